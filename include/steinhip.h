@@ -1,0 +1,162 @@
+/* steinhip.h -- C ABI of libsteinhip.so, the MI355X (gfx950) SVGD particle-update engine.
+ *
+ * The reference (JamesBrofos/Stein, pure Python) has no FFI layer; its seams on this path are
+ * Python duck-typed calls.  Every entry point below names the reference call it replaces
+ * (file:line relative to the reference tree).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (row-major, contiguous) unless the name ends in _host;
+ *     the library never allocates or frees caller memory.  Scratch comes from a caller-owned
+ *     workspace sized by stein_workspace_bytes() and described by stein_workspace_layout().
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); none of them
+ *     synchronises with the host.
+ *   - return value: 0 on success, a negative STEIN_E_* code otherwise; stein_last_error()
+ *     returns a per-thread message for the last failure.
+ *   - n = total number of particles, d = parameters per particle.  A rank owns rows
+ *     [row0, row0 + n_local) of theta / score / phi / optimizer state; single GPU: row0 = 0,
+ *     n_local = n.
+ */
+#ifndef STEINHIP_H
+#define STEINHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEIN_VERSION 100 /* 0.1.0 */
+
+enum {
+  STEIN_OK = 0,
+  STEIN_E_BADARG = -1,
+  STEIN_E_SHAPE = -2,
+  STEIN_E_WORKSPACE = -3,
+  STEIN_E_HIP = -4,
+  STEIN_E_RCCL = -5, /* reserved: collectives are issued by the host layer through torch.distributed */
+  STEIN_E_UNSUPPORTED = -6
+};
+
+/* element types of caller buffers */
+enum { STEIN_F32 = 0, STEIN_BF16 = 1, STEIN_F64 = 2 };
+
+/* flags for stein_svgd_phi / stein_workspace_bytes */
+enum {
+  STEIN_FLAG_NONE = 0
+};
+
+/* Workspace sections reported by stein_workspace_layout (byte offsets into the workspace). */
+enum {
+  STEIN_WS_ROWNORM = 0,  /* float  [n]                      r_i = |theta_i|^2                     */
+  STEIN_WS_DIST = 1,     /* float  [n_local][ld_dist]       squared distances, row block          */
+  STEIN_WS_HIST = 2,     /* int64  [3 levels][2][2048]      radix-select histograms               */
+  STEIN_WS_SELECT = 3,   /* 64 B   select state (ranks, prefixes, median, h2)                     */
+  STEIN_WS_PART_G = 4,   /* float  [split][n_local][d]      partial K.G                           */
+  STEIN_WS_PART_T = 5,   /* float  [split][n_local][d]      partial K.theta                       */
+  STEIN_WS_PART_RS = 6,  /* float  [split][n_local]         partial rowsum(K)                     */
+  STEIN_WS_SQPART = 7,   /* double [sq_blocks]              per-block partial |phi|^2             */
+  STEIN_WS_BF16 = 8,     /* bf16 staging copies (bf16 mode only)                                  */
+  STEIN_WS_NSECTIONS = 9
+};
+/* extra[] entries reported by stein_workspace_layout */
+enum { STEIN_WSX_LD_DIST = 0, STEIN_WSX_SPLIT = 1, STEIN_WSX_SQ_BLOCKS = 2, STEIN_WSX_HIST_BINS = 3, STEIN_WSX_N = 4 };
+
+#define STEIN_HIST_BINS 2048
+#define STEIN_HIST_LEVELS 3
+
+int stein_version(void);
+const char* stein_last_error(void);
+
+/* Workspace sizing. */
+int stein_workspace_bytes(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, size_t* out_bytes);
+int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags,
+                           size_t* offsets /*[STEIN_WS_NSECTIONS]*/, int64_t* extra /*[STEIN_WSX_N]*/);
+
+/* ---- fused single-rank path ------------------------------------------------------------------
+ * Replaces AbstractSteinSampler.compute_phi (stein/samplers/abstract_stein_sampler.py:100-105)
+ * together with everything it calls: SquaredExponentialKernel.kernel_and_grad
+ * (stein/kernels/squared_exponential_kernel.py:25-35), the distance / bandwidth graph
+ * (stein/kernels/abstract_kernel.py:30-40) and compute_median (stein/utilities/compute_median.py:4-16).
+ *   theta_all, score_all : [n][d] of `dtype` (STEIN_F32 or STEIN_BF16)
+ *   phi_local            : [n_local][d] float, rows row0..row0+n_local      (unclipped phi)
+ *   h2_out               : float[1], receives bandwidth^2
+ *   sqnorm_out           : double[1], receives sum(phi_local^2) (the rank-local part of |phi|_F^2)
+ *   K_out / dK_out       : optional (may be NULL): [n_local][n] float / [n_local][d] float
+ * Valid only when n_local == n (one rank sees every row, so the median is global).
+ */
+int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int64_t d,
+                   int64_t row0, int64_t n_local, int dtype,
+                   float* phi_local, float* h2_out, double* sqnorm_out,
+                   float* K_out, float* dK_out,
+                   void* workspace, size_t ws_bytes, int flags, void* stream);
+
+/* ---- staged path (tests, multi-rank: the host puts collectives between the stages) ------------ */
+
+/* r_i = sum_k theta_ik^2            abstract_kernel.py:34 */
+int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float* r_out, void* stream);
+
+/* D[i][j] = r_i + r_j - 2 <theta_i, theta_j>, rows row0..row0+n_local, all n columns.
+ * abstract_kernel.py:35.  dist_out has leading dimension ld_dist (>= n, multiple of 4). */
+int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d,
+                         int64_t row0, int64_t n_local, int dtype,
+                         float* dist_out, int64_t ld_dist, void* stream);
+
+/* Exact median of all n*n distances by 3-level radix select on the fp32 bit pattern.
+ * compute_median.py:4-16 (tf.nn.top_k of n^2//2+1 values; even count -> mean of the two middle).
+ *   begin   : zero the histograms, set the two target ranks for `total` values in all
+ *             (the path uses total = n*n; even -> ranks total/2-1 and total/2)
+ *   hist    : add this rank's row block to level `level`'s histogram
+ *   resolve : pick the digit holding each target rank (run after the histograms of all ranks
+ *             have been summed); at the last level writes median and h2 = sqrt(med/ln n)^2
+ *             (abstract_kernel.py:40, squared_exponential_kernel.py:22) into the select state
+ *             and to h2_out.
+ */
+int stein_median_begin(void* hist, void* select_state, int64_t total, void* stream);
+int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
+                           const void* select_state, void* hist, void* stream);
+int stein_median_resolve(const void* hist, int level, int64_t n, void* select_state,
+                         float* h2_out, float* median_out, void* stream);
+
+/* K = exp(-D / h2 / 2)               squared_exponential_kernel.py:22 (optional output) */
+int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n,
+                        const float* h2_dev, float* K_out, int64_t ld_K, void* stream);
+
+/* phi rows of this rank:  (K.G + (rowsum(K) theta - K.theta)/h2) / n
+ * squared_exponential_kernel.py:23,32 (dK) and abstract_stein_sampler.py:105 (phi).
+ * Fused exp + fp32-MFMA contraction over the materialised distance block, then a finish pass. */
+int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
+                          int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                          const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
+                          void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- optimizer apply ---------------------------------------------------------------------------
+ * Fuses the norm clip  phi *= 10 / max(10, |phi|_F)  (abstract_stein_sampler.py:125), the optimizer
+ * map and  theta += step  (abstract_stein_sampler.py:126).
+ *   sqnorm_dev  : device double[1] holding the GLOBAL |phi|_F^2, or NULL to use clip_scale_host
+ *   theta       : [count] of state_dtype, updated in place; may be NULL (state + step_out only:
+ *                 this is `gd.update(phi)` on its own)
+ *   step_out    : optional [count] of state_dtype, receives the step
+ *   state_dtype : STEIN_F32 or STEIN_F64 for theta / optimizer state / step_out (phi is float)
+ * Adagrad: stein/optimizers/adagrad_gradient_descent.py:37-44 (first_step -> hist = phi^2).
+ * Adam   : stein/optimizers/adam_gradient_descent.py:45-58 (t = n_iters AFTER increment;
+ *          t == 1 -> mu = phi, nu = phi^2); the caller multiplies lr by decay afterwards.
+ */
+int stein_apply_adagrad(void* theta, const float* phi, void* hist, int64_t count, int state_dtype,
+                        const double* sqnorm_dev, double clip_scale_host, double clip_threshold,
+                        double lr, double alpha, double eps, int first_step,
+                        void* step_out, void* stream);
+int stein_apply_adam(void* theta, const float* phi, void* mu, void* nu, int64_t count, int state_dtype,
+                     const double* sqnorm_dev, double clip_scale_host, double clip_threshold,
+                     double lr, double beta1, double beta2, double eps, int64_t t,
+                     void* step_out, void* stream);
+
+/* small helpers used by the host layer */
+int stein_cast_f64_to_f32(const double* src, float* dst, int64_t count, void* stream);
+int stein_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEINHIP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of libsteinhip.so (the C ABI declared in include/steinhip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an
+exception is raised.  Device pointers are taken from PyTorch-ROCm tensors with
+``.data_ptr()``; PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsteinhip.so")
+
+OK, E_BADARG, E_SHAPE, E_WORKSPACE, E_HIP, E_RCCL, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+F32, BF16, F64 = 0, 1, 2
+
+WS_ROWNORM, WS_DIST, WS_HIST, WS_SELECT, WS_PART_G, WS_PART_T, WS_PART_RS, WS_SQPART, WS_BF16 = range(9)
+WS_NSECTIONS = 9
+WSX_LD_DIST, WSX_SPLIT, WSX_SQ_BLOCKS, WSX_HIST_BINS = range(4)
+WSX_N = 4
+HIST_BINS, HIST_LEVELS = 2048, 3
+
+_c = ctypes
+_vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.c_size_t
+
+# name -> argtypes; every function returns int except the two noted below
+_SIGNATURES = {
+    "stein_workspace_bytes": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz)],
+    "stein_workspace_layout": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz), _c.POINTER(_i64)],
+    "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
+    "stein_rownorms": [_vp, _i64, _i64, _int, _vp, _vp],
+    "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
+    "stein_median_begin": [_vp, _vp, _i64, _vp],
+    "stein_median_hist_pass": [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
+    "stein_median_resolve": [_vp, _int, _i64, _vp, _vp, _vp, _vp],
+    "stein_kernel_matrix": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp],
+    "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "stein_apply_adagrad": [_vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp],
+    "stein_apply_adam": [_vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],
+    "stein_cast_f64_to_f32": [_vp, _vp, _i64, _vp],
+    "stein_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["stein_version", "stein_last_error"])
+
+_lib = None
+
+
+class SteinHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libsteinhip error %d: %s" % (code, message))
+        self.code = code
+
+
+def load():
+    """Load the library once.  Raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsteinhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "stein_amd has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, _int
+    lib.stein_version.argtypes, lib.stein_version.restype = [], _int
+    lib.stein_last_error.argtypes, lib.stein_last_error.restype = [], _c.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().stein_last_error().decode("utf-8", "replace")
+        if rc in (E_BADARG, E_SHAPE, E_UNSUPPORTED):
+            raise ValueError("libsteinhip error %d: %s" % (rc, msg))
+        raise SteinHipError(rc, msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def workspace_layout(n_local, n, d, dtype=F32, flags=0):
+    """-> (total_bytes, offsets[WS_NSECTIONS], extra[WSX_N]).  Pure host arithmetic, no GPU needed."""
+    total = _sz(0)
+    call("stein_workspace_bytes", n_local, n, d, dtype, flags, ctypes.byref(total))
+    offs = (_sz * WS_NSECTIONS)()
+    extra = (_i64 * WSX_N)()
+    call("stein_workspace_layout", n_local, n, d, dtype, flags, offs, extra)
+    return int(total.value), [int(o) for o in offs], [int(e) for e in extra]
+
+
+def version():
+    return load().stein_version()

@@ -1,0 +1,925 @@
+// steinhip.hip -- gfx950 (MI355X / CDNA4) kernels and C ABI for the SVGD particle update.
+//
+// Pipeline for one step on one rank (rows [row0, row0+n_local) of n particles, d parameters):
+//   k_rownorms      r_i = |theta_i|^2                                   HBM-bound, 4nd bytes
+//   k_distance      D = r_i + r_j - 2 theta theta^T  (fp32 MFMA 32x32x2, 128x128 tiles, LDS staged)
+//   k_hist x3       3-level radix select over the fp32 bit patterns of D (exact median)
+//   k_resolve x3    1-wave kernel that walks the histogram; last level -> median, h^2
+//   k_phi_partial   P = exp(-D/2h^2) built on the fly from the D tile, O += P.[G|theta] (fp32 MFMA),
+//                   rowsum(P) on the VALU -- K is never materialised
+//   k_phi_finish    phi = (O_G + (rowsum*theta - O_T)/h^2)/n, per-block partial |phi|^2 (fp64)
+//   k_sum_partials  deterministic reduction of the partials
+//   k_apply_*       clip + Adagrad/Adam + theta += step, one streaming pass
+// Reference formulae: see include/steinhip.h for the file:line of each stage.
+//
+// Everything is launched on the caller's stream; nothing here synchronises with the host.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+
+#include "steinhip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(STEIN_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define LAUNCH_CHECK(name)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) return fail(STEIN_E_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" int stein_version(void) { return STEIN_VERSION; }
+extern "C" const char* stein_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// tiling constants shared by the two MFMA kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128;        // rows of the output tile per workgroup
+constexpr int BN = 128;        // columns of the output tile per workgroup
+constexpr int BK = 32;         // contraction depth staged per iteration
+constexpr int LDK = BK + 4;    // LDS row stride (floats) of a [rows][k] tile: +16 B keeps ds_read_b128 conflict-free
+constexpr int NTHREADS = 256;  // 4 waves, arranged 2x2, each owning a 64x64 sub-tile = 2x2 MFMA 32x32 tiles
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one contiguous range of
+// logical tile ids so neighbouring tiles (which share operand panels) hit the same L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Row-of-k tile loader: rows `rbase + lr + 32p`, k range [k0 + lc, +4).  VEC requires d % 4 == 0.
+template <bool VEC>
+__device__ __forceinline__ void load_rows_k(const float* __restrict__ M, int nrows, int d, int rbase, int k0,
+                                            int lr, int lc, float4 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = rbase + lr + 32 * p;
+    const int k = k0 + lc;
+    if (VEC) {
+      v[p] = ld4_or_zero(M + (size_t)row * d + k, row < nrows && k < d);
+    } else {
+      const float* src = M + (size_t)row * d + k;
+      const bool rok = row < nrows;
+      v[p].x = (rok && k + 0 < d) ? src[0] : 0.f;
+      v[p].y = (rok && k + 1 < d) ? src[1] : 0.f;
+      v[p].z = (rok && k + 2 < d) ? src[2] : 0.f;
+      v[p].w = (rok && k + 3 < d) ? src[3] : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_rows_k(float* S, int lr, int lc, const float4 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(S + (lr + 32 * p) * LDK + lc) = v[p];
+}
+
+__device__ __forceinline__ float comp(const float4& v, int t) {
+  return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_rownorms: one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rownorms(const float* __restrict__ T, int n, int d, float* __restrict__ r) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const float* row = T + (size_t)wave * d;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) s = fmaf(row[k], row[k], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) r[wave] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_distance: D = r_i + r_j - 2 T T^T on the fp32 matrix cores.
+//   A operand = rows of the row block, B operand = rows of the column block, both k-contiguous, so both
+//   tiles live in LDS as [row][k] and a lane fetches 4 consecutive k with one ds_read_b128.  The k order
+//   inside an MFMA step is permuted identically for A and B (lane half h, step t <-> k = 8kk + 4h + t).
+//   Every D_ij runs the same k-ordered fma chain with the operands swapped for D_ji, so D is bitwise
+//   symmetric.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__ T, const float* __restrict__ r,
+                                                       float* __restrict__ D, int n, int d, int row0, int n_local,
+                                                       long ldD, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  // grouped tile order inside each XCD's contiguous range: 8 row tiles x all column tiles
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = logical / per_group;
+  const int first_m = g * GROUP;
+  const int gsize = min(tiles_m - first_m, GROUP);
+  const int in_g = logical - g * per_group;
+  const int tile_m = first_m + in_g % gsize;
+  const int tile_n = in_g / gsize;
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wy = wid >> 1, wx = wid & 1;
+  const int lr = t >> 3, lc = (t & 7) * 4;
+  const int arow0 = row0 + tile_m * BM;  // global particle index of the tile's first row
+  const int brow0 = tile_n * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[4], rb[4];
+  load_rows_k<VEC>(T, n, d, arow0, 0, lr, lc, ra);
+  load_rows_k<VEC>(T, n, d, brow0, 0, lr, lc, rb);
+
+  const int l31 = lane & 31, h4 = (lane >> 5) * 4;
+  for (int k0 = 0; k0 < d; k0 += BK) {
+    store_rows_k(As, lr, lc, ra);
+    store_rows_k(Bs, lr, lc, rb);
+    __syncthreads();
+    if (k0 + BK < d) {  // next tile's loads fly under this tile's MFMAs
+      load_rows_k<VEC>(T, n, d, arow0, k0 + BK, lr, lc, ra);
+      load_rows_k<VEC>(T, n, d, brow0, k0 + BK, lr, lc, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const float4*>(As + (wy * 64 + i * 32 + l31) * LDK + kk * 8 + h4);
+        b[i] = *reinterpret_cast<const float4*>(Bs + (wx * 64 + i * 32 + l31) * LDK + kk * 8 + h4);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[i], s), comp(b[j], s), acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = brow0 + wx * 64 + j * 32 + l31;
+      if (col >= n) continue;
+      const float rj = r[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lrow = tile_m * BM + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + h4;  // row inside this rank's block
+        if (lrow < n_local) {
+          const float ri = r[row0 + lrow];
+          D[(size_t)lrow * ldD + col] = (ri + rj) - 2.f * acc[i][j][e];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix select: keys, state, histogram pass, resolve
+// ------------------------------------------------------------------------------------------------
+struct SelState {
+  u64 rank[2];     // remaining 0-based ascending rank of each target inside its current prefix
+  u32 prefix[2];   // key bits fixed so far
+  u32 diverged;    // the two targets no longer share a prefix
+  u32 even;        // n*n even -> median is the mean of the two targets
+  float median;
+  float h2;
+  float lo, hi;    // the two order statistics
+  u32 pad[4];
+};
+static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
+
+__device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
+  const u32 u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(u32 k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void k_sel_init(SelState* st, u64 total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const u32 even = (total & 1ull) ? 0u : 1u;
+    st->rank[0] = even ? total / 2 - 1 : total / 2;
+    st->rank[1] = total / 2;
+    st->prefix[0] = st->prefix[1] = 0u;
+    st->diverged = 0u;
+    st->even = even;
+    st->median = st->h2 = st->lo = st->hi = 0.f;
+  }
+}
+
+// Add `valid` lanes' digits to an LDS histogram.  Distances cluster (a handful of top-level bins hold
+// everything), so the wave first merges lanes that share the leader's digit into one atomic, twice,
+// and only the stragglers fall back to per-lane atomics.
+__device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const u64 act = __ballot(valid);
+    if (act == 0ull) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const u32 ld = __shfl(digit, leader);
+    const bool same = valid && digit == ld;
+    const u64 m = __ballot(same);
+    if (lane == leader) atomicAdd(&h[ld], (u32)__popcll(m));
+    valid = valid && !same;
+  }
+  if (valid) atomicAdd(&h[digit], 1u);
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
+                                              const SelState* __restrict__ st, u64* __restrict__ hist) {
+  __shared__ u32 h[2 * STEIN_HIST_BINS];
+  for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
+  __syncthreads();
+
+  const u32 pa = st->prefix[0], pb = st->prefix[1];
+  const bool two = st->diverged != 0u;
+  const int lane = threadIdx.x & 63;
+  const int segs = (n + 1023) / 1024;
+  const long units = (long)n_local * segs;
+  for (long u = blockIdx.x; u < units; u += gridDim.x) {
+    const int row = (int)(u / segs);
+    const int c0 = (int)(u - (long)row * segs) * 1024 + threadIdx.x * 4;
+    float4 v = ld4_or_zero(D + (size_t)row * ldD + c0, c0 < n);  // ldD % 4 == 0, so the float4 stays inside the row
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool inb = c0 + e < n;
+      const u32 key = f32_key(x[e]);
+      u32 digit, hi;
+      if (LEVEL == 0) { digit = key >> 21; hi = 0u; }
+      else if (LEVEL == 1) { digit = (key >> 10) & 2047u; hi = key >> 21; }
+      else { digit = key & 1023u; hi = key >> 10; }
+      hist_add(h, digit, inb && (LEVEL == 0 || hi == pa), lane);
+      if (LEVEL != 0 && two) hist_add(h + STEIN_HIST_BINS, digit, inb && hi == pb, lane);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
+    if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
+}
+
+// one wave; hist points at this level's [2][STEIN_HIST_BINS] counters (already summed over ranks)
+__global__ __launch_bounds__(64) void k_resolve(const u64* __restrict__ hist, int level, SelState* st, float ln_n,
+                                                float* h2_out, float* median_out) {
+  __shared__ u64 bins[STEIN_HIST_BINS];
+  __shared__ u64 chunk[64];
+  const int lane = threadIdx.x;
+  const int bits = level == 2 ? 10 : 11;
+  const bool div_in = st->diverged != 0u;
+  u32 newp[2];
+  u64 newr[2];
+  for (int tg = 0; tg < 2; ++tg) {
+    const u64* src = hist + ((div_in && tg == 1) ? STEIN_HIST_BINS : 0);
+    u64 s = 0;
+    for (int b = 0; b < 32; ++b) {
+      const u64 c = src[lane * 32 + b];
+      bins[lane * 32 + b] = c;
+      s += c;
+    }
+    chunk[lane] = s;
+    __syncthreads();
+    if (lane == 0) {
+      u64 rank = st->rank[tg], cum = 0;
+      int c = 0;
+      while (c < 63 && cum + chunk[c] <= rank) cum += chunk[c++];
+      int b = c * 32;
+      const int bend = b + 31;
+      while (b < bend && cum + bins[b] <= rank) cum += bins[b++];
+      newp[tg] = (st->prefix[tg] << bits) | (u32)b;
+      newr[tg] = rank - cum;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    st->prefix[0] = newp[0]; st->prefix[1] = newp[1];
+    st->rank[0] = newr[0]; st->rank[1] = newr[1];
+    st->diverged = (newp[0] != newp[1]) ? 1u : 0u;
+    if (level == 2) {
+      const float lo = key_f32(newp[0]), hi = key_f32(newp[1]);
+      const float med = st->even ? 0.5f * (lo + hi) : lo;
+      const float bw = sqrtf(med / ln_n);      // abstract_kernel.py:40
+      const float h2 = bw * bw;                // squared_exponential_kernel.py:22 squares it again
+      st->lo = lo; st->hi = hi; st->median = med; st->h2 = h2;
+      if (h2_out) *h2_out = h2;
+      if (median_out) *median_out = med;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_kernel_matrix: optional K output, K = exp(-D / h2 / 2)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kernel_matrix(const float* __restrict__ D, long ldD, int n_local, int n,
+                                                       const float* __restrict__ h2p, float* __restrict__ K, long ldK) {
+  const float h2 = *h2p;
+  const long total = (long)n_local * n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / n, col = e - row * n;
+    K[row * ldK + col] = expf(-D[row * ldD + col] / h2 / 2.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_phi_partial: O[z] = P[:, jrange(z)] . V[jrange(z), cblock],  P = exp2(c D) built tile by tile.
+//   A operand = P tile [128 rows][32 j], written to LDS as [row][j] right after the exp, read back with
+//   ds_read_b128 (same k permutation as k_distance).  B operand = V tile [32 j][128 c], row-major in LDS;
+//   a lane reads V[j = 8kk + 4h + s][c = lane & 31] with ds_read_b32 (32 consecutive floats per half wave).
+//   The thread that stages P(row, 4 j) keeps the running rowsum for that row.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__device__ __forceinline__ void load_v_tile(const float* __restrict__ V, int n, int d, int j0, int jend, int c0,
+                                            int vr, int vc, float4 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int j = j0 + vr + 8 * p;
+    const int c = c0 + vc;
+    const bool jok = j < jend;
+    if (VEC) {
+      v[p] = ld4_or_zero(V + (size_t)j * d + c, jok && c < d);
+    } else {
+      const float* src = V + (size_t)j * d + c;
+      v[p].x = (jok && c + 0 < d) ? src[0] : 0.f;
+      v[p].y = (jok && c + 1 < d) ? src[1] : 0.f;
+      v[p].z = (jok && c + 2 < d) ? src[2] : 0.f;
+      v[p].w = (jok && c + 3 < d) ? src[3] : 0.f;
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(NTHREADS) void k_phi_partial(const float* __restrict__ D, long ldD,
+                                                          const float* __restrict__ G, const float* __restrict__ T,
+                                                          const float* __restrict__ h2p, float* __restrict__ OG,
+                                                          float* __restrict__ OT, float* __restrict__ RS, int n, int d,
+                                                          int n_local, int tiles_m, int cblocks, int split, int jchunk) {
+  __shared__ __attribute__((aligned(16))) float smem[BM * LDK + BK * BN];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ncb = 2 * cblocks;
+  const int cb = logical % ncb;
+  const int tile_m = (logical / ncb) % tiles_m;
+  const int z = logical / (ncb * tiles_m);
+  const bool isT = cb >= cblocks;
+  const float* __restrict__ V = isT ? T : G;
+  float* __restrict__ O = isT ? OT : OG;
+  const int c0 = (isT ? cb - cblocks : cb) * BN;
+
+  const int jbeg = z * jchunk;
+  const int jend = min(n, jbeg + jchunk);
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wy = wid >> 1, wx = wid & 1;
+  const int lr = t >> 3, lc = (t & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
+  const int vr = t >> 5, vc = (t & 31) * 4;  // V staging: j rows vr + 8p, 4 consecutive c
+  const int i0 = tile_m * BM;
+
+  const float cexp = -1.44269504088896341f / (2.f * *h2p);  // exp(-D/(2 h2)) = exp2(cexp * D)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  float4 rd[4], rv[4];
+  auto load_d = [&](int j0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = i0 + lr + 32 * p;
+      rd[p] = ld4_or_zero(D + (size_t)row * ldD + j0 + lc, row < n_local && j0 + lc < jend);
+    }
+  };
+  if (jbeg < jend) {
+    load_d(jbeg);
+    load_v_tile<VEC>(V, n, d, jbeg, jend, c0, vr, vc, rv);
+  }
+
+  const int l31 = lane & 31, h4 = (lane >> 5) * 4;
+  for (int j0 = jbeg; j0 < jend; j0 += BK) {
+    // P = exp2(cexp * D) for in-range j, 0 outside; stage to LDS, keep the rowsum
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int j = j0 + lc;
+      float4 pv;
+      pv.x = (j + 0 < jend) ? __builtin_amdgcn_exp2f(cexp * rd[p].x) : 0.f;
+      pv.y = (j + 1 < jend) ? __builtin_amdgcn_exp2f(cexp * rd[p].y) : 0.f;
+      pv.z = (j + 2 < jend) ? __builtin_amdgcn_exp2f(cexp * rd[p].z) : 0.f;
+      pv.w = (j + 3 < jend) ? __builtin_amdgcn_exp2f(cexp * rd[p].w) : 0.f;
+      if (i0 + lr + 32 * p >= n_local) pv = make_float4(0.f, 0.f, 0.f, 0.f);
+      rs[p] += (pv.x + pv.y) + (pv.z + pv.w);
+      *reinterpret_cast<float4*>(As + (lr + 32 * p) * LDK + lc) = pv;
+      *reinterpret_cast<float4*>(Bs + (vr + 8 * p) * BN + vc) = rv[p];
+    }
+    __syncthreads();
+    if (j0 + BK < jend) {
+      load_d(j0 + BK);
+      load_v_tile<VEC>(V, n, d, j0 + BK, jend, c0, vr, vc, rv);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const float4*>(As + (wy * 64 + i * 32 + l31) * LDK + kk * 8 + h4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Bs[(kk * 8 + h4 + s) * BN + wx * 64 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[i], s), b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // partial O tile
+  float* Oz = O + (size_t)z * n_local * d;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = c0 + wx * 64 + j * 32 + l31;
+      if (col >= d) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + h4;
+        if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e];
+      }
+    }
+  }
+  // rowsum: the 8 threads of a row are 8 consecutive lanes
+  if (cb == 0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float s = rs[p];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const int row = i0 + lr + 32 * p;
+      if ((t & 7) == 0 && row < n_local) RS[(size_t)z * n_local + row] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_phi_finish: sum the split partials, form phi, per-block partial |phi|^2 in fp64
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG, const float* __restrict__ OT,
+                                                    const float* __restrict__ RS, const float* __restrict__ T,
+                                                    const float* __restrict__ h2p, float* __restrict__ phi,
+                                                    float* __restrict__ dK, double* __restrict__ sqpart, int n, int d,
+                                                    int row0, int n_local, int split) {
+  __shared__ double red[4];
+  const float h2 = *h2p;
+  const float fn = (float)n;
+  const long total = (long)n_local * d;
+  const size_t zs = (size_t)n_local * d;
+  double sq = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / d);
+    float og = 0.f, ot = 0.f, rs = 0.f;
+    for (int z = 0; z < split; ++z) {
+      og += OG[z * zs + e];
+      ot += OT[z * zs + e];
+      rs += RS[(size_t)z * n_local + i];
+    }
+    const float th = T[(size_t)row0 * d + e];
+    const float dk = (rs * th - ot) / h2;
+    const float ph = (og + dk) / fn;
+    phi[e] = ph;
+    if (dK) dK[e] = dk;
+    sq += (double)ph * (double)ph;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) sqpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, int count, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) s += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer apply (clip + map + theta += step); arithmetic in fp64, storage S = float or double
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double clip_scale_of(const double* sq, double host_scale, double thr) {
+  if (!sq) return host_scale;
+  const double nrm = sqrt(*sq);
+  return thr / (nrm > thr ? nrm : thr);
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, const float* __restrict__ phi,
+                                                       S* __restrict__ hist, long count, const double* sq,
+                                                       double host_scale, double thr, double lr, double alpha,
+                                                       double eps, int first, S* __restrict__ step_out) {
+  const double scale = clip_scale_of(sq, host_scale, thr);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256) {
+    const double p = (double)phi[e] * scale;
+    const double hs = first ? p * p : alpha * (double)hist[e] + (1.0 - alpha) * p * p;
+    hist[e] = (S)hs;
+    const double step = p / (eps + sqrt(hs)) * lr;
+    if (step_out) step_out[e] = (S)step;
+    if (theta) theta[e] = (S)((double)theta[e] + step);
+  }
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_apply_adam(S* __restrict__ theta, const float* __restrict__ phi,
+                                                    S* __restrict__ mu, S* __restrict__ nu, long count,
+                                                    const double* sq, double host_scale, double thr, double lr,
+                                                    double b1, double b2, double eps, int first, double corr1,
+                                                    double corr2, S* __restrict__ step_out) {
+  const double scale = clip_scale_of(sq, host_scale, thr);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256) {
+    const double p = (double)phi[e] * scale;
+    const double m = first ? p : b1 * (double)mu[e] + (1.0 - b1) * p;
+    const double v = first ? p * p : b2 * (double)nu[e] + (1.0 - b2) * p * p;
+    mu[e] = (S)m;
+    nu[e] = (S)v;
+    const double step = (m / corr1) / (eps + sqrt(v / corr2)) * lr;
+    if (step_out) step_out[e] = (S)step;
+    if (theta) theta[e] = (S)((double)theta[e] + step);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cast_f64_f32(const double* __restrict__ s, float* __restrict__ o, long count) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256) o[e] = (float)s[e];
+}
+__global__ __launch_bounds__(256) void k_cast_f32_bf16(const float* __restrict__ s, __hip_bfloat16* __restrict__ o,
+                                                       long count) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256)
+    o[e] = __float2bfloat16(s[e]);
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+namespace {
+
+struct Layout {
+  size_t off[STEIN_WS_NSECTIONS];
+  size_t total;
+  int64_t ld_dist, split, sq_blocks, jchunk, tiles_m, cblocks;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, Layout* L) {
+  if (n < 2) return fail(STEIN_E_BADARG, "n = %lld: the bandwidth divides by ln(n), need n >= 2", (long long)n);
+  if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
+  if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
+  if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
+  L->ld_dist = (int64_t)align_up((size_t)n, 64);
+  L->tiles_m = (n_local + BM - 1) / BM;
+  L->cblocks = (d + BN - 1) / BN;
+  const int64_t base = L->tiles_m * 2 * L->cblocks;
+  const int64_t jt = (n + BK - 1) / BK;  // j tiles
+  int64_t split = (768 + base - 1) / base;
+  const int64_t max_split = jt / 8 > 0 ? jt / 8 : 1;  // at least 8 j-tiles (256 columns) per split
+  if (split > max_split) split = max_split;
+  if (split > 16) split = 16;
+  if (split < 1) split = 1;
+  const int64_t tiles_per = (jt + split - 1) / split;
+  L->jchunk = tiles_per * BK;
+  split = (jt + tiles_per - 1) / tiles_per;  // drop empty tails
+  L->split = split;
+  const int64_t elems = n_local * d;
+  int64_t sqb = (elems + 1023) / 1024;
+  if (sqb > 1024) sqb = 1024;
+  L->sq_blocks = sqb;
+
+  size_t at = 0;
+  auto put = [&](int sec, size_t bytes) { L->off[sec] = at; at = align_up(at + bytes, 256); };
+  put(STEIN_WS_ROWNORM, (size_t)n * 4);
+  put(STEIN_WS_DIST, (size_t)n_local * L->ld_dist * 4);
+  put(STEIN_WS_HIST, (size_t)STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS * 8);
+  put(STEIN_WS_SELECT, sizeof(SelState));
+  put(STEIN_WS_PART_G, (size_t)split * n_local * d * 4);
+  put(STEIN_WS_PART_T, (size_t)split * n_local * d * 4);
+  put(STEIN_WS_PART_RS, (size_t)split * n_local * 4);
+  put(STEIN_WS_SQPART, (size_t)sqb * 8);
+  put(STEIN_WS_BF16, dtype == STEIN_BF16 ? (size_t)2 * n * d * 4 : 0);
+  L->total = at;
+  return STEIN_OK;
+}
+
+inline int grid_for(long count, int cap) {
+  long b = (count + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int stein_workspace_bytes(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, size_t* out) {
+  (void)flags;
+  if (!out) return fail(STEIN_E_BADARG, "out is NULL");
+  Layout L;
+  int rc = make_layout(n_local, n, d, dtype, &L);
+  if (rc) return rc;
+  *out = L.total;
+  return STEIN_OK;
+}
+
+extern "C" int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, size_t* offsets,
+                                      int64_t* extra) {
+  (void)flags;
+  if (!offsets || !extra) return fail(STEIN_E_BADARG, "NULL output");
+  Layout L;
+  int rc = make_layout(n_local, n, d, dtype, &L);
+  if (rc) return rc;
+  for (int i = 0; i < STEIN_WS_NSECTIONS; ++i) offsets[i] = L.off[i];
+  extra[STEIN_WSX_LD_DIST] = L.ld_dist;
+  extra[STEIN_WSX_SPLIT] = L.split;
+  extra[STEIN_WSX_SQ_BLOCKS] = L.sq_blocks;
+  extra[STEIN_WSX_HIST_BINS] = STEIN_HIST_BINS;
+  return STEIN_OK;
+}
+
+extern "C" int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float* r_out, void* stream) {
+  if (!theta_all || !r_out) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (n < 1 || d < 1) return fail(STEIN_E_SHAPE, "bad shape");
+  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "rownorms: dtype %d", dtype);
+  const int blocks = (int)((n + 3) / 4);
+  hipLaunchKernelGGL(k_rownorms, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta_all, (int)n,
+                     (int)d, r_out);
+  LAUNCH_CHECK("k_rownorms");
+  return STEIN_OK;
+}
+
+extern "C" int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
+                                    int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* stream) {
+  if (!theta_all || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (n < 1 || d < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
+  if (ld_dist < n || (ld_dist & 3)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 4");
+  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "distance: dtype %d", dtype);
+  const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
+  const long nblk = (long)tiles_m * tiles_n;
+  if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
+  const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(k_distance<true>, dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream,
+                       (const float*)theta_all, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local,
+                       (long)ld_dist, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL(k_distance<false>, dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream,
+                       (const float*)theta_all, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local,
+                       (long)ld_dist, tiles_m, tiles_n);
+  LAUNCH_CHECK("k_distance");
+  return STEIN_OK;
+}
+
+extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total, void* stream) {
+  if (!hist || !select_state) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (total < 1) return fail(STEIN_E_SHAPE, "total < 1");
+  HIP_TRY(hipMemsetAsync(hist, 0, (size_t)STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS * 8, (hipStream_t)stream));
+  hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, (hipStream_t)stream, (SelState*)select_state,
+                     (u64)total);
+  LAUNCH_CHECK("k_sel_init");
+  return STEIN_OK;
+}
+
+extern "C" int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
+                                      const void* select_state, void* hist, void* stream) {
+  if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
+  if (ld_dist < n || (ld_dist & 3) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape");
+  const long segs = (n + 1023) / 1024;
+  long units = (long)n_local * segs;
+  const int blocks = (int)(units < 2048 ? units : 2048);
+  u64* h = (u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
+  const SelState* st = (const SelState*)select_state;
+  hipStream_t s = (hipStream_t)stream;
+  if (level == 0)
+    hipLaunchKernelGGL(k_hist<0>, dim3(blocks), dim3(256), 0, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  else if (level == 1)
+    hipLaunchKernelGGL(k_hist<1>, dim3(blocks), dim3(256), 0, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  else
+    hipLaunchKernelGGL(k_hist<2>, dim3(blocks), dim3(256), 0, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  LAUNCH_CHECK("k_hist");
+  return STEIN_OK;
+}
+
+extern "C" int stein_median_resolve(const void* hist, int level, int64_t n, void* select_state, float* h2_out,
+                                    float* median_out, void* stream) {
+  if (!hist || !select_state) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
+  if (n < 2) return fail(STEIN_E_BADARG, "n = %lld: need n >= 2", (long long)n);
+  const u64* h = (const u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
+  const float ln_n = (float)log((double)n);  // np.log(n) in fp64, cast to fp32 by the tf.float32 graph
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, h, level, (SelState*)select_state, ln_n,
+                     h2_out, median_out);
+  LAUNCH_CHECK("k_resolve");
+  return STEIN_OK;
+}
+
+extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n,
+                                   const float* h2_dev, float* K_out, int64_t ld_K, void* stream) {
+  if (!dist || !h2_dev || !K_out) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (ld_dist < n || ld_K < n || n_local < 1) return fail(STEIN_E_SHAPE, "bad shape");
+  hipLaunchKernelGGL(k_kernel_matrix, dim3(grid_for((long)n_local * n, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     dist, (long)ld_dist, (int)n_local, (int)n, h2_dev, K_out, (long)ld_K);
+  LAUNCH_CHECK("k_kernel_matrix");
+  return STEIN_OK;
+}
+
+extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
+                                     int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                                     const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+  if (!dist || !theta_all || !score_all || !h2_dev || !phi_local || !sqnorm_out || !workspace)
+    return fail(STEIN_E_BADARG, "NULL pointer");
+  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
+  if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
+  Layout L;
+  int rc = make_layout(n_local, n, d, dtype, &L);
+  if (rc) return rc;
+  if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  if (ld_dist != L.ld_dist) return fail(STEIN_E_SHAPE, "ld_dist %lld != %lld", (long long)ld_dist, (long long)L.ld_dist);
+  char* ws = (char*)workspace;
+  float* OG = (float*)(ws + L.off[STEIN_WS_PART_G]);
+  float* OT = (float*)(ws + L.off[STEIN_WS_PART_T]);
+  float* RS = (float*)(ws + L.off[STEIN_WS_PART_RS]);
+  double* SQ = (double*)(ws + L.off[STEIN_WS_SQPART]);
+  const float* T = (const float*)theta_all;
+  const float* G = (const float*)score_all;
+  hipStream_t s = (hipStream_t)stream;
+  const long nblk = (long)L.tiles_m * 2 * L.cblocks * L.split;
+  if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
+  const bool vec = (d % 4 == 0) && (((uintptr_t)T & 15) == 0) && (((uintptr_t)G & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(k_phi_partial<true>, dim3((unsigned)nblk), dim3(NTHREADS), 0, s, dist, (long)ld_dist, G, T,
+                       h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m, (int)L.cblocks, (int)L.split,
+                       (int)L.jchunk);
+  else
+    hipLaunchKernelGGL(k_phi_partial<false>, dim3((unsigned)nblk), dim3(NTHREADS), 0, s, dist, (long)ld_dist, G, T,
+                       h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m, (int)L.cblocks, (int)L.split,
+                       (int)L.jchunk);
+  LAUNCH_CHECK("k_phi_partial");
+  hipLaunchKernelGGL(k_phi_finish, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS, T, h2_dev, phi_local,
+                     dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local, (int)L.split);
+  LAUNCH_CHECK("k_phi_finish");
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, SQ, (int)L.sq_blocks, sqnorm_out);
+  LAUNCH_CHECK("k_sum_partials");
+  return STEIN_OK;
+}
+
+extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0,
+                              int64_t n_local, int dtype, float* phi_local, float* h2_out, double* sqnorm_out,
+                              float* K_out, float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
+  (void)flags;
+  if (!theta_all || !score_all || !phi_local || !h2_out || !sqnorm_out || !workspace)
+    return fail(STEIN_E_BADARG, "NULL pointer");
+  if (row0 != 0 || n_local != n)
+    return fail(STEIN_E_BADARG, "stein_svgd_phi is the single-rank path (row0 = 0, n_local = n); use the staged calls");
+  Layout L;
+  int rc = make_layout(n_local, n, d, dtype, &L);
+  if (rc) return rc;
+  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "svgd_phi: dtype %d not built yet", dtype);
+  if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  char* ws = (char*)workspace;
+  float* r = (float*)(ws + L.off[STEIN_WS_ROWNORM]);
+  float* D = (float*)(ws + L.off[STEIN_WS_DIST]);
+  void* hist = ws + L.off[STEIN_WS_HIST];
+  void* sel = ws + L.off[STEIN_WS_SELECT];
+  if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
+  if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, stream))) return rc;
+  if ((rc = stein_median_begin(hist, sel, n * n, stream))) return rc;
+  for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv) {
+    if ((rc = stein_median_hist_pass(D, L.ld_dist, n_local, n, lv, sel, hist, stream))) return rc;
+    if ((rc = stein_median_resolve(hist, lv, n, sel, h2_out, nullptr, stream))) return rc;
+  }
+  if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;
+  return stein_kernel_contract(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, phi_local,
+                               sqnorm_out, dK_out, workspace, ws_bytes, stream);
+}
+
+template <typename S>
+static int apply_adagrad_t(void* theta, const float* phi, void* hist, int64_t count, const double* sq, double hs,
+                           double thr, double lr, double alpha, double eps, int first, void* step_out, void* stream) {
+  hipLaunchKernelGGL(k_apply_adagrad<S>, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, (S*)theta,
+                     phi, (S*)hist, (long)count, sq, hs, thr, lr, alpha, eps, first, (S*)step_out);
+  LAUNCH_CHECK("k_apply_adagrad");
+  return STEIN_OK;
+}
+
+extern "C" int stein_apply_adagrad(void* theta, const float* phi, void* hist, int64_t count, int state_dtype,
+                                   const double* sqnorm_dev, double clip_scale_host, double clip_threshold, double lr,
+                                   double alpha, double eps, int first_step, void* step_out, void* stream) {
+  if (!phi || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (count < 1) return fail(STEIN_E_SHAPE, "count < 1");
+  if (state_dtype == STEIN_F32)
+    return apply_adagrad_t<float>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha, eps,
+                                  first_step, step_out, stream);
+  if (state_dtype == STEIN_F64)
+    return apply_adagrad_t<double>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha,
+                                   eps, first_step, step_out, stream);
+  return fail(STEIN_E_UNSUPPORTED, "state dtype %d", state_dtype);
+}
+
+template <typename S>
+static int apply_adam_t(void* theta, const float* phi, void* mu, void* nu, int64_t count, const double* sq, double hs,
+                        double thr, double lr, double b1, double b2, double eps, int64_t t, void* step_out,
+                        void* stream) {
+  const double corr1 = 1.0 - pow(b1, (double)t), corr2 = 1.0 - pow(b2, (double)t);
+  hipLaunchKernelGGL(k_apply_adam<S>, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, (S*)theta, phi,
+                     (S*)mu, (S*)nu, (long)count, sq, hs, thr, lr, b1, b2, eps, t == 1 ? 1 : 0, corr1, corr2,
+                     (S*)step_out);
+  LAUNCH_CHECK("k_apply_adam");
+  return STEIN_OK;
+}
+
+extern "C" int stein_apply_adam(void* theta, const float* phi, void* mu, void* nu, int64_t count, int state_dtype,
+                                const double* sqnorm_dev, double clip_scale_host, double clip_threshold, double lr,
+                                double beta1, double beta2, double eps, int64_t t, void* step_out, void* stream) {
+  if (!phi || !mu || !nu) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (count < 1 || t < 1) return fail(STEIN_E_SHAPE, "count < 1 or t < 1");
+  if (state_dtype == STEIN_F32)
+    return apply_adam_t<float>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
+                               beta2, eps, t, step_out, stream);
+  if (state_dtype == STEIN_F64)
+    return apply_adam_t<double>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
+                                beta2, eps, t, step_out, stream);
+  return fail(STEIN_E_UNSUPPORTED, "state dtype %d", state_dtype);
+}
+
+extern "C" int stein_cast_f64_to_f32(const double* src, float* dst, int64_t count, void* stream) {
+  if (!src || !dst) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (count < 1) return fail(STEIN_E_SHAPE, "count < 1");
+  hipLaunchKernelGGL(k_cast_f64_f32, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     (long)count);
+  LAUNCH_CHECK("k_cast_f64_f32");
+  return STEIN_OK;
+}
+
+extern "C" int stein_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream) {
+  if (!src || !dst) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (count < 1) return fail(STEIN_E_SHAPE, "count < 1");
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, src,
+                     (__hip_bfloat16*)dst, (long)count);
+  LAUNCH_CHECK("k_cast_f32_bf16");
+  return STEIN_OK;
+}

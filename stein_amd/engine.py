@@ -1,0 +1,166 @@
+"""Host-side orchestration of one SVGD direction computation (phi) on one rank.
+
+The arithmetic lives in libsteinhip.so; this module owns device buffers (PyTorch
+tensors), the caller-owned workspace, and -- when particles are sharded over
+ranks -- the collectives between the staged calls (torch.distributed, i.e. RCCL
+over xGMI on the GPU box):
+
+    all_gather(theta rows), all_gather(score rows)          once per step
+    all_reduce(level histogram)  x3                          median select
+    all_reduce(|phi|^2 partial)                              norm clip
+
+Rank p owns rows [p*n/P, (p+1)*n/P) of theta / score / phi / optimizer state and
+never sees more than its own [n/P, n] block of the distance matrix; K and D never
+cross a link.  Mirrors the single call at
+stein/samplers/abstract_stein_sampler.py:103-105 (K, dK = kernel_and_grad; phi).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    raise RuntimeError("libsteinhip stages need device (cuda/HIP) tensors; got a %s tensor. "
+                       "stein_amd has no CPU path." % t.device)
+
+
+class HipStages:
+    """The staged C-ABI calls on torch device tensors (the only product backend)."""
+
+    name = "hip"
+
+    def workspace_layout(self, n_local, n, d):
+        return _lib.workspace_layout(n_local, n, d, _lib.F32, 0)
+
+    def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws):
+        _lib.call("stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _lib.F32, _ptr(phi), _ptr(h2), _ptr(sqnorm),
+                  _ptr(K), _ptr(dK), _ptr(ws), ws.numel(), 0, _stream(T))
+
+    def rownorms(self, T, n, d, r):
+        _lib.call("stein_rownorms", _ptr(T), n, d, _lib.F32, _ptr(r), _stream(T))
+
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld):
+        _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _lib.F32, _ptr(D), ld, _stream(T))
+
+    def median_begin(self, hist, sel, total):
+        _lib.call("stein_median_begin", _ptr(hist), _ptr(sel), total, _stream(hist))
+
+    def median_hist_pass(self, D, ld, n_local, n, level, sel, hist):
+        _lib.call("stein_median_hist_pass", _ptr(D), ld, n_local, n, level, _ptr(sel), _ptr(hist), _stream(D))
+
+    def median_resolve(self, hist, level, n, sel, h2, median):
+        _lib.call("stein_median_resolve", _ptr(hist), level, n, _ptr(sel), _ptr(h2), _ptr(median), _stream(hist))
+
+    def kernel_matrix(self, D, ld, n_local, n, h2, K):
+        _lib.call("stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
+
+    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+        _lib.call("stein_kernel_contract", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _lib.F32, _ptr(h2),
+                  _ptr(phi), _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), _stream(D))
+
+
+class SvgdEngine:
+    """phi for the rows this rank owns.
+
+    Parameters
+    ----------
+    n, d    : total particle count and parameters per particle.
+    device  : torch device of every buffer.
+    group   : torch.distributed process group (None -> single rank).  n must divide evenly.
+    stages  : backend implementing the staged calls; the product default is HipStages.
+              (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
+    """
+
+    def __init__(self, n, d, device="cuda", group=None, stages=None):
+        self.n, self.d = int(n), int(d)
+        self.device = torch.device(device)
+        self.stages = stages if stages is not None else HipStages()
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        if self.n < 2:
+            raise ValueError("n_particles = %d: the median-heuristic bandwidth divides by ln(n); need n >= 2" % self.n)
+        if self.n % self.world:
+            raise ValueError("n_particles (%d) must be divisible by the number of ranks (%d)" % (self.n, self.world))
+        self.n_local = self.n // self.world
+        self.row0 = self.rank * self.n_local
+
+        total, offs, extra = self.stages.workspace_layout(self.n_local, self.n, self.d)
+        self.ws_bytes, self._offs = total, offs
+        self.ld_dist, self.split = extra[_lib.WSX_LD_DIST], extra[_lib.WSX_SPLIT]
+        dev = self.device
+        self.ws = torch.empty(total, dtype=torch.uint8, device=dev)
+        self.phi = torch.empty(self.n_local, self.d, dtype=torch.float32, device=dev)
+        self.h2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.median = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+        if self.world > 1:
+            self.T_all = torch.empty(self.n, self.d, dtype=torch.float32, device=dev)
+            self.G_all = torch.empty(self.n, self.d, dtype=torch.float32, device=dev)
+
+    # views into the workspace -------------------------------------------------------------
+    def _section(self, sec, nbytes, dtype):
+        o = self._offs[sec]
+        return self.ws[o:o + nbytes].view(dtype)
+
+    @property
+    def rownorm(self):
+        return self._section(_lib.WS_ROWNORM, self.n * 4, torch.float32)
+
+    @property
+    def dist(self):
+        return self._section(_lib.WS_DIST, self.n_local * self.ld_dist * 4, torch.float32).view(self.n_local, self.ld_dist)
+
+    @property
+    def hist(self):
+        nb = _lib.HIST_LEVELS * 2 * _lib.HIST_BINS * 8
+        return self._section(_lib.WS_HIST, nb, torch.int64).view(_lib.HIST_LEVELS, 2, _lib.HIST_BINS)
+
+    @property
+    def select_state(self):
+        return self._section(_lib.WS_SELECT, 64, torch.uint8)
+
+    # ---------------------------------------------------------------------------------------
+    def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None):
+        """theta_local, score_local: [n_local, d] float32 contiguous device tensors (this rank's rows).
+
+        Returns self.phi ([n_local, d] float32, unclipped).  Afterwards self.h2 holds bandwidth^2
+        and self.sqnorm the GLOBAL |phi|_F^2 (fp64), both on device; nothing syncs with the host.
+        """
+        st, n, d, nl = self.stages, self.n, self.d, self.n_local
+        for name, t in (("theta", theta_local), ("score", score_local)):
+            if tuple(t.shape) != (nl, d) or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous float32 [%d, %d] tensor, got %s %s" %
+                                 (name, nl, d, tuple(t.shape), t.dtype))
+        if self.world == 1:
+            st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws)
+            return self.phi
+
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.T_all, theta_local, group=self.group)
+        dist.all_gather_into_tensor(self.G_all, score_local, group=self.group)
+        D, ld, hist, sel = self.dist, self.ld_dist, self.hist, self.select_state
+        st.rownorms(self.T_all, n, d, self.rownorm)
+        st.distance_block(self.T_all, self.rownorm, n, d, self.row0, nl, D, ld)
+        st.median_begin(hist, sel, n * n)
+        for level in range(_lib.HIST_LEVELS):
+            st.median_hist_pass(D, ld, nl, n, level, sel, hist)
+            dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
+            st.median_resolve(hist, level, n, sel, self.h2, self.median)
+        if K_out is not None:
+            st.kernel_matrix(D, ld, nl, n, self.h2, K_out)
+        st.kernel_contract(D, ld, self.T_all, self.G_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm,
+                           dK_out, self.ws)
+        dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+        return self.phi
