@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- SVGD particle-updates/s on MI355X, with the MFMA roofline of the dominant kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full particle update given the score matrix G (resident in HBM): row norms -> fp32-MFMA
+distance block -> exact median (3-level radix select) -> fused exp + fp32-MFMA contraction K.[G|theta]
+-> phi, |phi|^2 -> clip + Adagrad apply (lr 1e-3, alpha 0.9).  Workload: BASELINE.json's roofline config
+"n=16384, d=256, fp32" (C3); with N ranks the same n is sharded by rows (strong scaling), one all-gather of
+theta and G rows, three histogram all-reduces and one scalar all-reduce per step over RCCL.
+
+value = n * K / (max-over-ranks wall time of the K timed steps), bracketed by barrier + synchronize.
+roofline: k_phi_partial (the K.[G|theta] contraction), algorithmic flops 4*n_local*n*d per launch (2*n^2*d for
+K.G plus 2*n^2*d for K.theta), duration from HIP events recorded around each of its launches
+on the launching stream inside the timed region; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md).
+cpu_baseline: the NumPy oracle (a port: the reference's TF-1.12 kernel graph cannot run anywhere here) timed
+on the host on a bounded row block of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md, chip-level parameters
+WORKLOADS = {
+    "c3": dict(n=16384, d=256, name="C3 bayesian-logreg-shaped synthetic block n=16384 d=256 fp32 (roofline config)"),
+    "c5": dict(n=131072, d=256, name="C5 n=131072 d=256 fp32, rows sharded over the ranks"),
+    "c2f32": dict(n=4096, d=128, name="C2-shaped n=4096 d=128 run in fp32"),
+    "c4": dict(n=8192, d=2001, name="C4 BNN-shaped n=8192 d=2001 (H=666) fp32"),
+    "c1": dict(n=100, d=10, name="C1 n=100 d=10"),
+}
+
+
+def make_inputs(n, d, row0, n_local, device, torch):
+    # T ~ N(0,1) seed 0, G ~ N(0,1) seed 1, generated in fp64 then cast
+    T = np.random.default_rng(0).normal(size=(n, d))
+    G = np.random.default_rng(1).normal(size=(n, d))
+    Tl = torch.tensor(T[row0:row0 + n_local], dtype=torch.float32, device=device).contiguous()
+    Gl = torch.tensor(G[row0:row0 + n_local], dtype=torch.float32, device=device).contiguous()
+    return T, G, Tl, Gl
+
+
+class StageClock:
+    """Records a HIP event (torch.cuda.Event on the launching = current stream) at every stage mark."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.steps = []
+        self.cur = None
+
+    def begin_step(self):
+        self.cur = []
+        self.steps.append(self.cur)
+
+    def mark(self, label):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.cur.append((label, ev))
+
+    def summary(self):
+        """-> {label: mean ms between this mark and the next one}"""
+        acc = {}
+        for marks in self.steps:
+            for (la, ea), (_, eb) in zip(marks[:-1], marks[1:]):
+                acc.setdefault(la, []).append(ea.elapsed_time(eb))
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmup, clock_stages=True):
+    from stein_amd.engine import SvgdEngine
+    from stein_amd.optimizers import AdagradGradientDescent
+    n, d = wl["n"], wl["d"]
+    n_local = n // world
+    row0 = rank * n_local
+    T64, G64, theta, G = make_inputs(n, d, row0, n_local, device, torch)
+    eng = SvgdEngine(n, d, device=device, group=group)
+    gd = AdagradGradientDescent(learning_rate=1e-3, alpha=0.9)
+    clock = StageClock(torch)
+
+    def step(timed):
+        if timed and clock_stages:
+            clock.begin_step()
+            phi = eng.compute_phi(theta, G, mark=clock.mark)
+            gd.apply_(theta, phi, eng.sqnorm)
+            clock.mark("apply_end")
+        else:
+            phi = eng.compute_phi(theta, G, mark=(lambda s: None) if clock_stages else None)
+            gd.apply_(theta, phi, eng.sqnorm)
+
+    for _ in range(warmup):
+        step(False)
+    if world > 1:
+        dist.barrier(group=group)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier(group=group)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(te.item())
+    stages = clock.summary() if clock_stages else {}
+    if "end" in stages:            # interval end -> apply_end is the optimizer apply kernel
+        stages["apply"] = stages.pop("end")
+    finite = bool(torch.isfinite(theta).all().item())
+    return dict(n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
+                ws_bytes=eng.ws_bytes, T64=T64, G64=G64)
+
+
+def cpu_baseline(wl, T64, G64, rows):
+    from oracle import svgd_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        info = threadpool_info()
+        cores = max([i.get("num_threads", 1) for i in info] or [1])
+        blas = ",".join(sorted({"%s %s" % (i.get("internal_api"), i.get("version")) for i in info}))
+    except Exception:
+        cores, blas = os.cpu_count() or 1, "unknown"
+    n, d = wl["n"], wl["d"]
+    rows = min(rows, n)
+    gd = orc.AdagradState(learning_rate=1e-3, alpha=0.9)
+    t0 = time.perf_counter()
+    orc.svgd_step_rows(T64, G64, 0, rows, gd, np.float32)
+    dt = time.perf_counter() - t0
+    return dict(value=rows / dt, unit="particle-updates/s", cores=int(cores), kind="port",
+                sample="one step of the NumPy oracle (fp32 kernel, fp64 contraction, %s) on rows [0,%d) of the same "
+                       "n=%d d=%d inputs: %.1f s of CPU work; the reference's TF-1.12 graph cannot run here" %
+                       (blas, rows, n, d, dt),
+                seconds=dt)
+
+
+def pmc_traffic(workload_key):
+    """HBM bytes per k_phi_partial launch from the committed PMC summary (profiles/pmc_traffic.json), if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(workload_key, {}).get("k_phi_partial_hbm_bytes")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path in stein_amd)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist, group = None, None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+        group = dist.group.WORLD
+
+    import __graft_entry__ as ge
+    ge.build()
+
+    wl = WORKLOADS[args.workload]
+    res = run_workload(torch, dist, args, wl, device, rank, world, group, args.steps, args.warmup)
+    n, d, nl = res["n"], res["d"], res["n_local"]
+    ms_per_step = res["elapsed"] / args.steps * 1e3
+    value = n * args.steps / res["elapsed"]
+    k_ms = res["stages"].get("contract")
+    flops = 4.0 * nl * n * d
+    achieved = flops / (k_ms * 1e-3) if k_ms else None
+    out = {
+        "metric": "SVGD particle-updates/sec",
+        "value": value,
+        "unit": "particle-updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wl["name"], "n": n, "d": d, "rows_per_rank": nl,
+                   "optimizer": "adagrad lr=1e-3 alpha=0.9",
+                   "parallelism": "rows sharded x%d, all-gather(theta,G)+3 hist all-reduce+1 scalar all-reduce" % world
+                   if world > 1 else "single GPU"},
+        "element_updates_per_s": value * d,
+        "pair_interactions_per_s": value * n,
+        "roofline": {
+            "kernel": "k_phi_partial (exp + fp32 MFMA K.[G|theta] contraction)",
+            "bound": "mfma", "achieved": achieved / 1e12 if achieved else None, "peak": PEAK_FP32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA if achieved else None,
+            "flops_per_launch": flops, "ms_per_launch": k_ms,
+            "traffic": pmc_traffic(args.workload) if world == 1 else None,
+        },
+        "stage_ms": {k: round(v, 4) for k, v in res["stages"].items()},
+        "full_step_tflops": 6.0 * nl * n * d / (ms_per_step * 1e-3) / 1e12,
+        "finite": res["finite"],
+    }
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, res["T64"], res["G64"], args.cpu_rows)
+    del res
+
+    if args.secondary != "none" and args.secondary != args.workload:
+        wl2 = WORKLOADS[args.secondary]
+        need = (wl2["n"] // world) * wl2["n"] * 4 * 1.15 + 4 * wl2["n"] * wl2["d"] * 8
+        free = torch.cuda.mem_get_info(device)[0]
+        if need < free * 0.9:
+            torch.cuda.empty_cache()
+            r2 = run_workload(torch, dist, args, wl2, device, rank, world, group, args.secondary_steps, 1)
+            k2 = r2["stages"].get("contract")
+            f2 = 4.0 * r2["n_local"] * r2["n"] * r2["d"]
+            out["secondary"] = {
+                "workload": wl2["name"], "n": r2["n"], "d": r2["d"], "steps": args.secondary_steps,
+                "ms_per_step": r2["elapsed"] / args.secondary_steps * 1e3,
+                "value": r2["n"] * args.secondary_steps / r2["elapsed"], "unit": "particle-updates/s",
+                "scaling": "strong (fixed n=%d)" % r2["n"],
+                "contract_tflops": f2 / (k2 * 1e-3) / 1e12 if k2 else None,
+                "stage_ms": {k: round(v, 4) for k, v in r2["stages"].items()}, "finite": r2["finite"],
+            }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(group=group)
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

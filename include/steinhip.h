@@ -131,6 +131,16 @@ int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
                           void* workspace, size_t ws_bytes, void* stream);
 
+/* The two halves of stein_kernel_contract, exposed so a harness can time the MFMA kernel on its own:
+ *   partial : k_phi_partial only (fills the PART_G / PART_T / PART_RS workspace sections)
+ *   finish  : sums the split partials, forms phi (and dK), reduces |phi|^2 */
+int stein_contract_partial(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
+                           int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                           const float* h2_dev, void* workspace, size_t ws_bytes, void* stream);
+int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                          const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
+                          void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- optimizer apply ---------------------------------------------------------------------------
  * Fuses the norm clip  phi *= 10 / max(10, |phi|_F)  (abstract_stein_sampler.py:125), the optimizer
  * map and  theta += step  (abstract_stein_sampler.py:126).

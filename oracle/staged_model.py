@@ -1,0 +1,141 @@
+"""NumPy model of the STAGED protocol (row-block distance, 3-level radix select with summed histograms,
+row-block contraction)  --  TEST INFRASTRUCTURE ONLY, never imported by stein_amd.
+
+Two uses:
+  * tests/test_radix_model.py checks the radix-select algorithm itself (key transform, two-target tracking,
+    even/odd handling) against np.partition, on CPU;
+  * tests/test_distributed_cpu.py plugs `NumpyStages` into stein_amd.engine.SvgdEngine in place of the HIP
+    backend so the multi-rank collective protocol (all-gather of rows, histogram all-reduce, |phi|^2
+    all-reduce, identical bandwidth on every rank) runs under gloo with world_size 2 on CPU.
+
+It mirrors the semantics of the C ABI in include/steinhip.h, not its performance structure.
+"""
+import numpy as np
+
+from . import svgd_oracle as orc
+
+BINS, LEVELS = 2048, 3
+SHIFT = (21, 10, 0)
+BITS = (11, 11, 10)
+
+
+def f32_keys(x):
+    """Monotone map fp32 -> uint32 (same as f32_key in steinhip.hip)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    neg = (u & np.uint32(0x80000000)) != 0
+    return np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def key_to_f32(k):
+    k = np.uint32(k)
+    u = (k & np.uint32(0x7FFFFFFF)) if (k & np.uint32(0x80000000)) else np.uint32(~k)
+    return np.array([u], dtype=np.uint32).view(np.float32)[0]
+
+
+class SelectState:
+    """What the 64-byte device struct holds."""
+
+    def __init__(self, total):
+        self.even = total % 2 == 0
+        self.rank = [total // 2 - 1 if self.even else total // 2, total // 2]
+        self.prefix = [0, 0]
+        self.diverged = False
+        self.median = self.h2 = None
+
+
+def hist_pass(values, level, st, hist):
+    """hist: int64 [2][BINS] for this level; adds the counts of `values` (any shape)."""
+    key = f32_keys(values).reshape(-1).astype(np.uint64)
+    digit = (key >> np.uint64(SHIFT[level])) & np.uint64((1 << BITS[level]) - 1)
+    hi = key >> np.uint64(SHIFT[level] + BITS[level]) if level > 0 else np.zeros_like(key)
+    for tg in range(2 if (st.diverged and level > 0) else 1):
+        sel = digit if level == 0 else digit[hi == np.uint64(st.prefix[tg])]
+        hist[tg] += np.bincount(sel.astype(np.int64), minlength=BINS)[:BINS]
+
+
+def resolve(hist, level, n, st):
+    div_in = st.diverged
+    for tg in range(2):
+        h = hist[1 if (div_in and tg == 1) else 0]
+        cum = np.cumsum(h)
+        b = int(np.searchsorted(cum, st.rank[tg], side="right"))
+        b = min(b, BINS - 1)
+        st.rank[tg] -= int(cum[b - 1]) if b > 0 else 0
+        st.prefix[tg] = (st.prefix[tg] << BITS[level]) | b
+    st.diverged = st.prefix[0] != st.prefix[1]
+    if level == LEVELS - 1:
+        lo, hi = key_to_f32(st.prefix[0]), key_to_f32(st.prefix[1])
+        st.median = np.float32(0.5) * (lo + hi) if st.even else lo
+        with np.errstate(invalid="ignore", divide="ignore"):
+            st.h2 = orc.bandwidth_sq(st.median, n, np.float32) if n >= 2 else None
+
+
+def radix_median(values):
+    """Exact median of all entries (compute_median semantics) via the 3-level select."""
+    total = int(np.asarray(values).size)
+    st = SelectState(total)
+    for level in range(LEVELS):
+        hist = np.zeros((2, BINS), dtype=np.int64)
+        hist_pass(values, level, st, hist)
+        resolve(hist, level, max(total, 2), st)
+    return st.median
+
+
+class NumpyStages:
+    """Stage backend with the HipStages interface, operating on CPU torch tensors through NumPy views."""
+
+    name = "numpy-model"
+
+    def __init__(self, layout_fn):
+        self._layout = layout_fn     # stein_amd._lib.workspace_layout (pure host arithmetic in the .so)
+        self._st = None
+        self._partial = None
+
+    def workspace_layout(self, n_local, n, d):
+        return self._layout(n_local, n, d)
+
+    def rownorms(self, T, n, d, r):
+        t = T.numpy()
+        r.numpy()[:] = (t * t).sum(axis=1)
+
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld):
+        t, rr = T.numpy(), r.numpy()
+        blk = rr[row0:row0 + n_local, None] + rr[None, :] - np.float32(2) * (t[row0:row0 + n_local] @ t.T)
+        D.numpy()[:, :n] = blk
+
+    def median_begin(self, hist, sel, total):
+        hist.zero_()
+        self._st = SelectState(total)
+
+    def median_hist_pass(self, D, ld, n_local, n, level, sel, hist):
+        hist_pass(D.numpy()[:n_local, :n], level, self._st, hist.numpy()[level])
+
+    def median_resolve(self, hist, level, n, sel, h2, median):
+        resolve(hist.numpy()[level], level, n, self._st)
+        if level == LEVELS - 1:
+            h2.numpy()[0] = self._st.h2
+            median.numpy()[0] = self._st.median
+
+    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws):
+        K = np.exp(-D.numpy()[:n_local, :n] / h2.numpy()[0] / np.float32(2)).astype(np.float64)
+        self._partial = (K @ G.numpy().astype(np.float64), K @ T.numpy().astype(np.float64), K.sum(axis=1))
+
+    def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+        kg, kt, rs = self._partial
+        th = T.numpy()[row0:row0 + n_local].astype(np.float64)
+        dk = (rs[:, None] * th - kt) / float(h2.numpy()[0])
+        ph = (kg + dk) / n
+        phi.numpy()[:] = ph
+        sqnorm.numpy()[0] = float((ph.astype(np.float32).astype(np.float64) ** 2).sum())
+        if dK is not None:
+            dK.numpy()[:] = dk
+
+    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+        self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws)
+        self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws)
+
+    def kernel_matrix(self, D, ld, n_local, n, h2, K):
+        K.numpy()[:] = np.exp(-D.numpy()[:n_local, :n] / h2.numpy()[0] / np.float32(2))
+
+    def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws):
+        raise RuntimeError("the model backend only implements the staged calls")

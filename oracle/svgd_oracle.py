@@ -214,3 +214,22 @@ def svgd_step(theta, grads, gd, dtype=np.float32):
     theta_new = np.asarray(theta, dtype=np.float64) + gd.update(phi_c)
     return dict(D=D, median=med, h2=h2, K=K, dK=dK, phi=phi, sqnorm=sq,
                 phi_clipped=phi_c, theta_new=theta_new)
+
+
+def svgd_step_rows(theta, grads, row0, m, gd, dtype=np.float32):
+    """The same step restricted to the row block [row0, row0+m): distances of those rows to all n particles,
+    the median of that block (a bounded stand-in for the n^2 select: same algorithm, m*n values), K rows,
+    phi rows, clip with the block's norm, optimizer apply on those rows.  Used by bench.py to time a BOUNDED
+    sample of a large workload on the host; every stage of the step is row-separable except the median,
+    whose cost is proportional to the number of values selected over."""
+    T = np.ascontiguousarray(theta, dtype=dtype)
+    n = T.shape[0]
+    Tb = T[row0:row0 + m]
+    r = np.sum(T * T, axis=1)
+    D = r[row0:row0 + m, None] + r[None, :] - dtype(2) * (Tb @ T.T)
+    h2 = bandwidth_sq(median_all(D), n, dtype)
+    K = np.exp(-D / h2 / dtype(2))
+    dK = (K.sum(axis=1)[:, None] * Tb - K @ T) / h2
+    phi = (K.dot(np.asarray(grads, dtype=np.float64)) + dK) / n
+    phi = phi * clip_scale(np.sum(phi * phi))
+    return np.asarray(theta[row0:row0 + m], dtype=np.float64) + gd.update(phi)

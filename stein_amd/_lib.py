@@ -34,6 +34,8 @@ _SIGNATURES = {
     "stein_median_resolve": [_vp, _int, _i64, _vp, _vp, _vp, _vp],
     "stein_kernel_matrix": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp],
     "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "stein_contract_partial": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp],
+    "stein_contract_finish": [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "stein_apply_adagrad": [_vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp],
     "stein_apply_adam": [_vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],
     "stein_cast_f64_to_f32": [_vp, _vp, _i64, _vp],

@@ -786,12 +786,11 @@ extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n
   return STEIN_OK;
 }
 
-extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
-                                     int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
-                                     const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
-                                     void* workspace, size_t ws_bytes, void* stream) {
-  if (!dist || !theta_all || !score_all || !h2_dev || !phi_local || !sqnorm_out || !workspace)
-    return fail(STEIN_E_BADARG, "NULL pointer");
+extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const void* theta_all,
+                                      const void* score_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
+                                      int dtype, const float* h2_dev, void* workspace, size_t ws_bytes,
+                                      void* stream) {
+  if (!dist || !theta_all || !score_all || !h2_dev || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
   if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   Layout L;
@@ -803,7 +802,6 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
   float* OG = (float*)(ws + L.off[STEIN_WS_PART_G]);
   float* OT = (float*)(ws + L.off[STEIN_WS_PART_T]);
   float* RS = (float*)(ws + L.off[STEIN_WS_PART_RS]);
-  double* SQ = (double*)(ws + L.off[STEIN_WS_SQPART]);
   const float* T = (const float*)theta_all;
   const float* G = (const float*)score_all;
   hipStream_t s = (hipStream_t)stream;
@@ -819,12 +817,42 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
                        h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m, (int)L.cblocks, (int)L.split,
                        (int)L.jchunk);
   LAUNCH_CHECK("k_phi_partial");
-  hipLaunchKernelGGL(k_phi_finish, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS, T, h2_dev, phi_local,
-                     dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local, (int)L.split);
+  return STEIN_OK;
+}
+
+extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
+                                     int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
+                                     float* dK_out, void* workspace, size_t ws_bytes, void* stream) {
+  if (!theta_all || !h2_dev || !phi_local || !sqnorm_out || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
+  if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
+  Layout L;
+  int rc = make_layout(n_local, n, d, dtype, &L);
+  if (rc) return rc;
+  if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  char* ws = (char*)workspace;
+  const float* OG = (const float*)(ws + L.off[STEIN_WS_PART_G]);
+  const float* OT = (const float*)(ws + L.off[STEIN_WS_PART_T]);
+  const float* RS = (const float*)(ws + L.off[STEIN_WS_PART_RS]);
+  double* SQ = (double*)(ws + L.off[STEIN_WS_SQPART]);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_phi_finish, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS, (const float*)theta_all,
+                     h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local, (int)L.split);
   LAUNCH_CHECK("k_phi_finish");
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, SQ, (int)L.sq_blocks, sqnorm_out);
   LAUNCH_CHECK("k_sum_partials");
   return STEIN_OK;
+}
+
+extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
+                                     int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                                     const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+  int rc = stein_contract_partial(dist, ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, workspace,
+                                  ws_bytes, stream);
+  if (rc) return rc;
+  return stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
+                               ws_bytes, stream);
 }
 
 extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0,

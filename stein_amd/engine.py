@@ -62,9 +62,17 @@ class HipStages:
     def kernel_matrix(self, D, ld, n_local, n, h2, K):
         _lib.call("stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
 
+    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws):
+        _lib.call("stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _lib.F32, _ptr(h2),
+                  _ptr(ws), ws.numel(), _stream(D))
+
+    def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+        _lib.call("stein_contract_finish", _ptr(T), n, d, row0, n_local, _lib.F32, _ptr(h2), _ptr(phi),
+                  _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), _stream(T))
+
     def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
-        _lib.call("stein_kernel_contract", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _lib.F32, _ptr(h2),
-                  _ptr(phi), _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), _stream(D))
+        self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws)
+        self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws)
 
 
 class SvgdEngine:
@@ -132,35 +140,55 @@ class SvgdEngine:
         return self._section(_lib.WS_SELECT, 64, torch.uint8)
 
     # ---------------------------------------------------------------------------------------
-    def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None):
+    def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None, mark=None):
         """theta_local, score_local: [n_local, d] float32 contiguous device tensors (this rank's rows).
 
         Returns self.phi ([n_local, d] float32, unclipped).  Afterwards self.h2 holds bandwidth^2
         and self.sqnorm the GLOBAL |phi|_F^2 (fp64), both on device; nothing syncs with the host.
+
+        mark: optional callable(label) invoked between stages on the launching stream (bench.py records
+        HIP events there to time individual kernels).  Passing it selects the staged calls, which launch
+        exactly the kernels of the fused call.
         """
         st, n, d, nl = self.stages, self.n, self.d, self.n_local
         for name, t in (("theta", theta_local), ("score", score_local)):
             if tuple(t.shape) != (nl, d) or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError("%s must be a contiguous float32 [%d, %d] tensor, got %s %s" %
                                  (name, nl, d, tuple(t.shape), t.dtype))
-        if self.world == 1:
+        if self.world == 1 and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws)
             return self.phi
+        if mark is None:
+            def mark(label):
+                return None
 
-        import torch.distributed as dist
-        dist.all_gather_into_tensor(self.T_all, theta_local, group=self.group)
-        dist.all_gather_into_tensor(self.G_all, score_local, group=self.group)
+        if self.world > 1:
+            import torch.distributed as dist
+            mark("gather")
+            dist.all_gather_into_tensor(self.T_all, theta_local, group=self.group)
+            dist.all_gather_into_tensor(self.G_all, score_local, group=self.group)
+            T_all, G_all = self.T_all, self.G_all
+        else:
+            T_all, G_all = theta_local, score_local
         D, ld, hist, sel = self.dist, self.ld_dist, self.hist, self.select_state
-        st.rownorms(self.T_all, n, d, self.rownorm)
-        st.distance_block(self.T_all, self.rownorm, n, d, self.row0, nl, D, ld)
+        mark("rownorms")
+        st.rownorms(T_all, n, d, self.rownorm)
+        mark("distance")
+        st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld)
+        mark("median")
         st.median_begin(hist, sel, n * n)
         for level in range(_lib.HIST_LEVELS):
             st.median_hist_pass(D, ld, nl, n, level, sel, hist)
-            dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
             st.median_resolve(hist, level, n, sel, self.h2, self.median)
         if K_out is not None:
             st.kernel_matrix(D, ld, nl, n, self.h2, K_out)
-        st.kernel_contract(D, ld, self.T_all, self.G_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm,
-                           dK_out, self.ws)
-        dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+        mark("contract")
+        st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws)
+        mark("finish")
+        st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws)
+        if self.world > 1:
+            dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+        mark("end")
         return self.phi

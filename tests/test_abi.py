@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads, exports every symbol the header declares, and its host-side argument
+checks work -- no compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from stein_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "steinhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(stein_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), "libsteinhip.so does not export %s" % name
+    assert set(declared) == set(_lib.EXPORTED_SYMBOLS), "ctypes table and header disagree"
+    assert _lib.version() == 100
+
+
+def test_workspace_layout_is_consistent():
+    for nl, n, d in [(100, 100, 10), (4096, 4096, 128), (16384, 16384, 256), (2048, 16384, 256), (8192, 8192, 2001),
+                     (16384, 131072, 256)]:
+        total, offs, extra = _lib.workspace_layout(nl, n, d)
+        assert offs == sorted(offs) and offs[-1] <= total
+        assert all(o % 256 == 0 for o in offs)
+        ld = extra[_lib.WSX_LD_DIST]
+        assert ld >= n and ld % 64 == 0
+        assert offs[_lib.WS_HIST] - offs[_lib.WS_DIST] >= nl * ld * 4
+        assert 1 <= extra[_lib.WSX_SPLIT] <= 16
+        assert extra[_lib.WSX_HIST_BINS] == _lib.HIST_BINS
+    # C3 fits comfortably: D is 1 GiB, everything else < 100 MiB
+    total, _, extra = _lib.workspace_layout(16384, 16384, 256)
+    assert (1 << 30) < total < (1 << 30) + (100 << 20)
+
+
+@pytest.mark.parametrize("args", [(1, 1, 8), (0, 8, 8), (9, 8, 8), (8, 8, 0)])
+def test_bad_shapes_are_refused_with_a_message(args):
+    with pytest.raises(ValueError) as e:
+        _lib.workspace_layout(*args)
+    assert "libsteinhip error" in str(e.value)
+
+
+def test_null_pointers_are_refused_before_any_launch():
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.stein_rownorms(null, 8, 8, _lib.F32, null, null) == _lib.E_BADARG
+    assert b"NULL" in lib.stein_last_error()
+    assert lib.stein_median_hist_pass(null, 8, 8, 8, 0, null, null, null) == _lib.E_BADARG
+    assert lib.stein_apply_adam(null, null, null, null, 8, _lib.F32, null, 1.0, 10.0, 1e-3, 0.9, 0.999, 1e-8, 1,
+                                null, null) == _lib.E_BADARG
+    total = ctypes.c_size_t(0)
+    assert lib.stein_workspace_bytes(8, 8, 8, 7, 0, ctypes.byref(total)) == _lib.E_UNSUPPORTED
+
+
+def test_product_package_does_not_import_the_oracle():
+    """The oracle is test infrastructure; nothing under stein_amd/ may reference it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "stein_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                assert "oracle" not in src, "%s mentions the oracle" % os.path.join(base, f)
+
+
+def test_stages_refuse_cpu_tensors():
+    import torch
+    from stein_amd.engine import HipStages
+    t = torch.zeros(8, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        HipStages().rownorms(t, 8, 4, torch.zeros(8))

@@ -1,0 +1,89 @@
+"""CPU, gloo, world_size 2: the multi-rank protocol of stein_amd.engine.SvgdEngine.
+
+The HIP stages cannot run without a GPU, so the engine is given the NumPy stage model
+(oracle/staged_model.py, test infrastructure).  What is under test is the PRODUCT host logic: row
+ownership, the all-gather of theta/score rows, the per-level histogram all-reduce that makes every rank
+resolve the same median, the |phi|^2 all-reduce, and that the sharded result equals the single-rank one.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, d, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stein_amd import _lib
+        from stein_amd.engine import SvgdEngine
+        from oracle.staged_model import NumpyStages
+        rng = np.random.default_rng(42)
+        T, G = rng.normal(size=(n, d)), rng.normal(size=(n, d))
+        eng = SvgdEngine(n, d, device="cpu", group=dist.group.WORLD, stages=NumpyStages(_lib.workspace_layout))
+        assert eng.n_local == n // world and eng.row0 == rank * eng.n_local
+        sl = slice(eng.row0, eng.row0 + eng.n_local)
+        th = torch.tensor(T[sl], dtype=torch.float32).contiguous()
+        sc = torch.tensor(G[sl], dtype=torch.float32).contiguous()
+        phi = eng.compute_phi(th, sc).clone()
+        # second call reuses every buffer (histograms must be re-zeroed)
+        phi2 = eng.compute_phi(th, sc).clone()
+        assert torch.equal(phi, phi2)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), phi=phi.numpy(), h2=eng.h2.numpy(),
+                 median=eng.median.numpy(), sqnorm=eng.sqnorm.numpy(), row0=eng.row0,
+                 gathered_ok=np.array(np.allclose(eng.T_all.numpy(), T.astype(np.float32))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,d", [(64, 6), (130, 9)])
+def test_two_rank_protocol_matches_single_rank(tmp_path, n, d):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
+    from oracle import svgd_oracle as orc
+    rng = np.random.default_rng(42)
+    T, G = rng.normal(size=(n, d)), rng.normal(size=(n, d))
+    T32, G32 = T.astype(np.float32).astype(np.float64), G.astype(np.float32).astype(np.float64)
+    ref = orc.svgd_step(T32, G32, orc.AdagradState(), np.float32)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert all(bool(p["gathered_ok"]) for p in parts)
+    # identical bandwidth / median / global norm on every rank
+    assert parts[0]["h2"][0] == parts[1]["h2"][0] == ref["h2"]
+    assert parts[0]["median"][0] == parts[1]["median"][0] == ref["median"]
+    assert parts[0]["sqnorm"][0] == parts[1]["sqnorm"][0]
+    phi = np.concatenate([p["phi"] for p in parts], axis=0)
+    np.testing.assert_allclose(phi, ref["phi"], rtol=0, atol=2e-6 * np.abs(ref["phi"]).max())
+    np.testing.assert_allclose(parts[0]["sqnorm"][0], ref["sqnorm"], rtol=1e-5)
+
+
+def test_uneven_sharding_is_refused():
+    from stein_amd import _lib
+    from stein_amd.engine import SvgdEngine
+    from oracle.staged_model import NumpyStages
+
+    class FakeGroup:
+        pass
+    import torch.distributed as d2
+    orig = (d2.get_world_size, d2.get_rank)
+    d2.get_world_size, d2.get_rank = (lambda g=None: 3), (lambda g=None: 0)
+    try:
+        with pytest.raises(ValueError, match="divisible"):
+            SvgdEngine(64, 4, device="cpu", group=FakeGroup(), stages=NumpyStages(_lib.workspace_layout))
+    finally:
+        d2.get_world_size, d2.get_rank = orig
