@@ -65,9 +65,9 @@ def test_c3_full_size_properties(cuda):
     phi = eng.compute_phi(T, G, dK_out=dK).clone()
     D = eng.dist[:, :n]
     assert torch.equal(D, D.T)
-    # select state: lo / hi order statistics live at float offsets 8 and 9 of the 64-byte struct
+    # select state: lo / hi order statistics follow the 32 bytes of ranks/prefixes/flags: floats 8..11 = median, h2, lo, hi
     st = eng.select_state.view(torch.float32)
-    med, h2, lo, hi = st[6].item(), st[7].item(), st[8].item(), st[9].item()
+    med, h2, lo, hi = st[8].item(), st[9].item(), st[10].item(), st[11].item()
     _exact_median_check(D, (lo, hi), n * n)
     assert med == np.float32(0.5) * (np.float32(lo) + np.float32(hi))
     bw = np.sqrt(np.float32(med) / np.float32(math.log(n)))
