@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=16384, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
     ap.add_argument("--secondary-steps", type=int, default=3)
