@@ -46,6 +46,12 @@ enum { STEIN_F32 = 0, STEIN_BF16 = 1, STEIN_F64 = 2 };
 enum {
   STEIN_FLAG_NONE = 0
 };
+/* flags for the staged distance / histogram calls */
+enum {
+  STEIN_STAGE_SYMMETRIC = 1 /* the block is the whole n x n matrix (row0 = 0, n_local = n): compute / count only the
+                               upper triangle; the distance pass stores each off-diagonal tile twice (mirrored) and
+                               the histograms weigh off-diagonal entries by 2.  Results are identical. */
+};
 
 /* Workspace sections reported by stein_workspace_layout (byte offsets into the workspace). */
 enum {
@@ -98,10 +104,13 @@ int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int6
 int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float* r_out, void* stream);
 
 /* D[i][j] = r_i + r_j - 2 <theta_i, theta_j>, rows row0..row0+n_local, all n columns.
- * abstract_kernel.py:35.  dist_out has leading dimension ld_dist (>= n, multiple of 4). */
+ * abstract_kernel.py:35.  dist_out has leading dimension ld_dist (>= n, multiple of 4).
+ * hist_level0: optional (NULL to skip) pointer to the level-0 histogram int64[2][2048] (zeroed by
+ * stein_median_begin): the kernel adds the level-0 counts of the entries it produces, which replaces
+ * stein_median_hist_pass(level 0).  flags: 0 or STEIN_STAGE_SYMMETRIC. */
 int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d,
                          int64_t row0, int64_t n_local, int dtype,
-                         float* dist_out, int64_t ld_dist, void* stream);
+                         float* dist_out, int64_t ld_dist, void* hist_level0, int flags, void* stream);
 
 /* Exact median of all n*n distances by 3-level radix select on the fp32 bit pattern.
  * compute_median.py:4-16 (tf.nn.top_k of n^2//2+1 values; even count -> mean of the two middle).
@@ -115,7 +124,7 @@ int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, i
  */
 int stein_median_begin(void* hist, void* select_state, int64_t total, void* stream);
 int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
-                           const void* select_state, void* hist, void* stream);
+                           const void* select_state, void* hist, int flags, void* stream);
 int stein_median_resolve(const void* hist, int level, int64_t n, void* select_state,
                          float* h2_out, float* median_out, void* stream);
 

@@ -98,16 +98,18 @@ class NumpyStages:
         t = T.numpy()
         r.numpy()[:] = (t * t).sum(axis=1)
 
-    def distance_block(self, T, r, n, d, row0, n_local, D, ld):
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False):
         t, rr = T.numpy(), r.numpy()
         blk = rr[row0:row0 + n_local, None] + rr[None, :] - np.float32(2) * (t[row0:row0 + n_local] @ t.T)
         D.numpy()[:, :n] = blk
+        if hist0 is not None:      # the HIP kernel takes the level-0 counts from its accumulators
+            hist_pass(blk, 0, self._st, hist0.numpy())
 
     def median_begin(self, hist, sel, total):
         hist.zero_()
         self._st = SelectState(total)
 
-    def median_hist_pass(self, D, ld, n_local, n, level, sel, hist):
+    def median_hist_pass(self, D, ld, n_local, n, level, sel, hist, symmetric=False):
         hist_pass(D.numpy()[:n_local, :n], level, self._st, hist.numpy()[level])
 
     def median_resolve(self, hist, level, n, sel, h2, median):

@@ -18,6 +18,7 @@ WS_NSECTIONS = 9
 WSX_LD_DIST, WSX_SPLIT, WSX_SQ_BLOCKS, WSX_HIST_BINS = range(4)
 WSX_N = 4
 HIST_BINS, HIST_LEVELS = 2048, 3
+STAGE_SYMMETRIC = 1
 
 _c = ctypes
 _vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.c_size_t
@@ -28,9 +29,9 @@ _SIGNATURES = {
     "stein_workspace_layout": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz), _c.POINTER(_i64)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_rownorms": [_vp, _i64, _i64, _int, _vp, _vp],
-    "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
+    "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _int, _vp],
     "stein_median_begin": [_vp, _vp, _i64, _vp],
-    "stein_median_hist_pass": [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp],
+    "stein_median_hist_pass": [_vp, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp],
     "stein_median_resolve": [_vp, _int, _i64, _vp, _vp, _vp, _vp],
     "stein_kernel_matrix": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp],
     "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

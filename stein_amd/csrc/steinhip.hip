@@ -18,6 +18,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
@@ -122,31 +123,100 @@ __global__ __launch_bounds__(256) void k_rownorms(const float* __restrict__ T, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// radix select: keys, state, histogram pass, resolve
+// ------------------------------------------------------------------------------------------------
+struct SelState {
+  u64 rank[2];     // remaining 0-based ascending rank of each target inside its current prefix
+  u32 prefix[2];   // key bits fixed so far
+  u32 diverged;    // the two targets no longer share a prefix
+  u32 even;        // n*n even -> median is the mean of the two targets
+  float median;
+  float h2;
+  float lo, hi;    // the two order statistics
+  u32 pad[4];
+};
+static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
+
+__device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
+  const u32 u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(u32 k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void k_sel_init(SelState* st, u64 total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const u32 even = (total & 1ull) ? 0u : 1u;
+    st->rank[0] = even ? total / 2 - 1 : total / 2;
+    st->rank[1] = total / 2;
+    st->prefix[0] = st->prefix[1] = 0u;
+    st->diverged = 0u;
+    st->even = even;
+    st->median = st->h2 = st->lo = st->hi = 0.f;
+  }
+}
+
+// Add `valid` lanes' digits to an LDS histogram.  Distances cluster (a handful of top-level bins hold
+// everything), so the wave first merges lanes that share the leader's digit into one atomic, twice,
+// and only the stragglers fall back to per-lane atomics.
+// `w` is the (wave-uniform) weight of every valid lane: 2 when an upper-triangle entry also stands for its mirror.
+__device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane, u32 w = 1u) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const u64 act = __ballot(valid);
+    if (act == 0ull) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const u32 ld = (u32)__builtin_amdgcn_readlane((int)digit, leader);
+    const bool same = valid && digit == ld;
+    const u64 m = __ballot(same);
+    if (lane == leader) atomicAdd(&h[ld], (u32)__popcll(m) * w);
+    valid = valid && !same;
+  }
+  if (valid) atomicAdd(&h[digit], w);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_distance: D = r_i + r_j - 2 T T^T on the fp32 matrix cores.
 //   A operand = rows of the row block, B operand = rows of the column block, both k-contiguous, so both
 //   tiles live in LDS as [row][k] and a lane fetches 4 consecutive k with one ds_read_b128.  The k order
 //   inside an MFMA step is permuted identically for A and B (lane half h, step t <-> k = 8kk + 4h + t).
 //   Every D_ij runs the same k-ordered fma chain with the operands swapped for D_ji, so D is bitwise
-//   symmetric.
+//   symmetric.  SYM (the block is the whole n x n matrix): only tiles on or above the diagonal are
+//   computed and each off-diagonal tile is also stored transposed -- half the MFMA work.
+//   hist0 != NULL: the level-0 radix-select histogram (top 11 key bits) is taken from the accumulators
+//   here instead of re-reading D; a mirrored tile counts twice.
 // ------------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool SYM>
 __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__ T, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int d, int row0, int n_local,
-                                                       long ldD, int tiles_m, int tiles_n) {
+                                                       long ldD, int tiles_m, int tiles_n, u64* __restrict__ hist0) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
-  // grouped tile order inside each XCD's contiguous range: 8 row tiles x all column tiles
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  constexpr int GROUP = 8;
-  const int per_group = GROUP * tiles_n;
-  const int g = logical / per_group;
-  const int first_m = g * GROUP;
-  const int gsize = min(tiles_m - first_m, GROUP);
-  const int in_g = logical - g * per_group;
-  const int tile_m = first_m + in_g % gsize;
-  const int tile_n = in_g / gsize;
+  int tile_m, tile_n;
+  if (SYM) {
+    // upper triangle, row by row: row tm holds tiles (tm, tm..t-1); first id of row tm = tm*t - tm(tm-1)/2
+    const int t_ = tiles_n;
+    int tm = (int)(((2.0 * t_ + 1.0) - sqrt((2.0 * t_ + 1.0) * (2.0 * t_ + 1.0) - 8.0 * (double)logical)) * 0.5);
+    tm = max(0, min(tm, t_ - 1));
+    while (tm > 0 && (long)tm * t_ - (long)tm * (tm - 1) / 2 > logical) --tm;
+    while ((long)(tm + 1) * t_ - (long)(tm + 1) * tm / 2 <= logical) ++tm;
+    tile_m = tm;
+    tile_n = tm + (logical - (int)((long)tm * t_ - (long)tm * (tm - 1) / 2));
+  } else {
+    // grouped tile order inside each XCD's contiguous range: 8 row tiles x all column tiles
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = logical / per_group;
+    const int first_m = g * GROUP;
+    const int gsize = min(tiles_m - first_m, GROUP);
+    const int in_g = logical - g * per_group;
+    tile_m = first_m + in_g % gsize;
+    tile_n = in_g / gsize;
+  }
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
@@ -194,80 +264,78 @@ __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__
     __syncthreads();
   }
 
-  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  u32* hl = reinterpret_cast<u32*>(smem);  // the staging tiles are dead: reuse 8 KB as the level-0 histogram
+  if (hist0) {
+    for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
+    __syncthreads();
+  }
+  const bool mirror = SYM && tile_m != tile_n;
+  const u32 weight = mirror ? 2u : 1u;
+  // Level-0 counting: the 64 values of a thread fall into a few neighbouring digits, so each thread keeps eight
+  // 8-bit counters (one 64-bit register) for the window [base-3, base+4] around its wave's first digit and touches
+  // the LDS histogram only once per window slot at the end; values outside the window go straight to LDS.
+  u64 packed = 0ull;
+  u32 base = 0u;
+  if (hist0) {
+    const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - 2.f * acc[0][0][0];
+    base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
+    base = base < 3u ? 0u : base - 3u;  // window start
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = brow0 + wx * 64 + j * 32 + l31;
-      if (col >= n) continue;
-      const float rj = r[col];
+      const bool cok = col < n;
+      const float rj = cok ? r[col] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int lrow = tile_m * BM + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + h4;  // row inside this rank's block
-        if (lrow < n_local) {
-          const float ri = r[row0 + lrow];
-          D[(size_t)lrow * ldD + col] = (ri + rj) - 2.f * acc[i][j][e];
+      for (int g = 0; g < 4; ++g) {
+        const int lrow4 = tile_m * BM + wy * 64 + i * 32 + 8 * g + h4;  // first of 4 consecutive rows (e & 3)
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lrow = lrow4 + q;
+          const bool ok = cok && lrow < n_local;
+          const float ri = lrow < n_local ? r[row0 + lrow] : 0.f;
+          v[q] = (ri + rj) - 2.f * acc[i][j][4 * g + q];
+          if (ok) D[(size_t)lrow * ldD + col] = v[q];
+          if (hist0 && ok) {
+            const u32 dg = f32_key(v[q]) >> 21;
+            const u32 off = dg - base;
+            if (off < 8u) packed += 1ull << (8u * off);
+            else atomicAdd(&hl[dg], weight);
+          }
         }
+        // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (16-byte aligned: ldD % 64 == 0,
+        // lrow4 % 4 == 0).  Entries past n land in the row's padding, which no later stage reads.
+        if (mirror && cok && lrow4 < n_local)
+          *reinterpret_cast<float4*>(D + (size_t)col * ldD + lrow4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// radix select: keys, state, histogram pass, resolve
-// ------------------------------------------------------------------------------------------------
-struct SelState {
-  u64 rank[2];     // remaining 0-based ascending rank of each target inside its current prefix
-  u32 prefix[2];   // key bits fixed so far
-  u32 diverged;    // the two targets no longer share a prefix
-  u32 even;        // n*n even -> median is the mean of the two targets
-  float median;
-  float h2;
-  float lo, hi;    // the two order statistics
-  u32 pad[4];
-};
-static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
-
-__device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
-  const u32 u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(u32 k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
-__global__ void k_sel_init(SelState* st, u64 total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const u32 even = (total & 1ull) ? 0u : 1u;
-    st->rank[0] = even ? total / 2 - 1 : total / 2;
-    st->rank[1] = total / 2;
-    st->prefix[0] = st->prefix[1] = 0u;
-    st->diverged = 0u;
-    st->even = even;
-    st->median = st->h2 = st->lo = st->hi = 0.f;
-  }
-}
-
-// Add `valid` lanes' digits to an LDS histogram.  Distances cluster (a handful of top-level bins hold
-// everything), so the wave first merges lanes that share the leader's digit into one atomic, twice,
-// and only the stragglers fall back to per-lane atomics.
-__device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane) {
+  if (hist0) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const u64 act = __ballot(valid);
-    if (act == 0ull) return;
-    const int leader = __ffsll((long long)act) - 1;
-    const u32 ld = __shfl(digit, leader);
-    const bool same = valid && digit == ld;
-    const u64 m = __ballot(same);
-    if (lane == leader) atomicAdd(&h[ld], (u32)__popcll(m));
-    valid = valid && !same;
+    for (int k = 0; k < 8; ++k) {
+      // wave-sum of slot k, then one LDS atomic per wave
+      u32 c = (u32)(packed >> (8 * k)) & 255u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if (lane == 0 && c) atomicAdd(&hl[base + k], c * weight);
+    }
+    __syncthreads();
+    for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS)
+      if (hl[b]) atomicAdd(&hist0[b], (u64)hl[b]);
   }
-  if (valid) atomicAdd(&h[digit], 1u);
 }
 
-template <int LEVEL>
+// ------------------------------------------------------------------------------------------------
+// radix select: histogram pass, resolve (keys, state and hist_add are defined above k_distance)
+// ------------------------------------------------------------------------------------------------
+// SYM (square symmetric block): only columns >= row are read; an off-diagonal entry counts twice.
+// Level 0 sees every value and a handful of bins hold them all -> wave-merged adds.  Levels 1-2 only see the
+// values inside the selected bin, spread over up to 2048 digits -> plain LDS atomics are cheaper.
+template <int LEVEL, bool SYM>
 __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
                                               const SelState* __restrict__ st, u64* __restrict__ hist) {
   __shared__ u32 h[2 * STEIN_HIST_BINS];
@@ -279,21 +347,34 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
   const int lane = threadIdx.x & 63;
   const int segs = (n + 1023) / 1024;
   const long units = (long)n_local * segs;
+  // unit u = (segment, row), segment-major, so a block's stride-gridDim walk samples rows evenly in every
+  // segment (with SYM the work per row shrinks towards the bottom of the matrix)
   for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const int row = (int)(u / segs);
-    const int c0 = (int)(u - (long)row * segs) * 1024 + threadIdx.x * 4;
-    float4 v = ld4_or_zero(D + (size_t)row * ldD + c0, c0 < n);  // ldD % 4 == 0, so the float4 stays inside the row
+    const int seg = (int)(u / n_local);
+    const int row = (int)(u - (long)seg * n_local);
+    if (SYM && (seg + 1) * 1024 <= row) continue;  // the whole segment lies left of the diagonal
+    const int c0 = seg * 1024 + threadIdx.x * 4;
+    float4 v = ld4_or_zero(D + (size_t)row * ldD + c0, c0 < n && (!SYM || c0 + 3 >= row));
     const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bool inb = c0 + e < n;
+      const int col = c0 + e;
+      const bool inb = col < n && (!SYM || col >= row);
       const u32 key = f32_key(x[e]);
-      u32 digit, hi;
-      if (LEVEL == 0) { digit = key >> 21; hi = 0u; }
-      else if (LEVEL == 1) { digit = (key >> 10) & 2047u; hi = key >> 21; }
-      else { digit = key & 1023u; hi = key >> 10; }
-      hist_add(h, digit, inb && (LEVEL == 0 || hi == pa), lane);
-      if (LEVEL != 0 && two) hist_add(h + STEIN_HIST_BINS, digit, inb && hi == pb, lane);
+      const u32 w = (SYM && col != row) ? 2u : 1u;
+      if (LEVEL == 0) {
+        if (SYM) {
+          hist_add(h, key >> 21, inb && col != row, lane, 2u);
+          if (inb && col == row) atomicAdd(&h[key >> 21], 1u);
+        } else {
+          hist_add(h, key >> 21, inb, lane);
+        }
+      } else {
+        const u32 digit = LEVEL == 1 ? ((key >> 10) & 2047u) : (key & 1023u);
+        const u32 hi = LEVEL == 1 ? (key >> 21) : (key >> 10);
+        if (inb && hi == pa) atomicAdd(&h[digit], w);
+        if (two && inb && hi == pb) atomicAdd(&h[STEIN_HIST_BINS + digit], w);
+      }
     }
   }
   __syncthreads();
@@ -636,11 +717,22 @@ int make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, Layout* L) {
   L->cblocks = (d + BN - 1) / BN;
   const int64_t base = L->tiles_m * 2 * L->cblocks;
   const int64_t jt = (n + BK - 1) / BK;  // j tiles
-  int64_t split = (768 + base - 1) / base;
-  const int64_t max_split = jt / 8 > 0 ? jt / 8 : 1;  // at least 8 j-tiles (256 columns) per split
-  if (split > max_split) split = max_split;
-  if (split > 16) split = 16;
-  if (split < 1) split = 1;
+  // k_phi_partial runs 3 workgroups per CU (156 registers): 768 resident blocks.  Every block does the same
+  // work, so the launch takes ceil(blocks / 768) rounds; pick the j-split that wastes least of the last round
+  // (ties -> fewer splits, i.e. less partial traffic), keeping at least 8 j-tiles (256 columns) per split.
+  int64_t max_split = jt / 8 > 0 ? jt / 8 : 1;
+  if (max_split > 16) max_split = 16;
+  int64_t split = 1;
+  double best = -1.0;
+  for (int64_t s = 1; s <= max_split; ++s) {
+    const double rounds = (double)(base * s) / 768.0;
+    const double eff = rounds / ceil(rounds) - 0.004 * (double)(s - 1);
+    if (eff > best + 1e-9) { best = eff; split = s; }
+  }
+  if (const char* e = getenv("STEIN_SPLIT")) {  // experiments only
+    const long v = atol(e);
+    if (v >= 1 && v <= max_split) split = v;
+  }
   const int64_t tiles_per = (jt + split - 1) / split;
   L->jchunk = tiles_per * BK;
   split = (jt + tiles_per - 1) / tiles_per;  // drop empty tails
@@ -710,24 +802,34 @@ extern "C" int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int d
   return STEIN_OK;
 }
 
+template <bool VEC, bool SYM>
+static void launch_distance(long nblk, hipStream_t s, const float* T, const float* r, float* D, int n, int d, int row0,
+                            int n_local, long ld, int tiles_m, int tiles_n, u64* hist0) {
+  hipLaunchKernelGGL((k_distance<VEC, SYM>), dim3((unsigned)nblk), dim3(NTHREADS), 0, s, T, r, D, n, d, row0, n_local,
+                     ld, tiles_m, tiles_n, hist0);
+}
+
 extern "C" int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
-                                    int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* stream) {
+                                    int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* hist_level0,
+                                    int flags, void* stream) {
   if (!theta_all || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (n < 1 || d < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   if (ld_dist < n || (ld_dist & 3)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 4");
   if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "distance: dtype %d", dtype);
+  const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
+  if (sym && (row0 != 0 || n_local != n || (ld_dist & 63)))
+    return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs the whole matrix (row0 = 0, n_local = n) and ld_dist %% 64 == 0");
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
-  const long nblk = (long)tiles_m * tiles_n;
+  const long nblk = sym ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
   if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
   const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
-  if (vec)
-    hipLaunchKernelGGL(k_distance<true>, dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream,
-                       (const float*)theta_all, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local,
-                       (long)ld_dist, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL(k_distance<false>, dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream,
-                       (const float*)theta_all, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local,
-                       (long)ld_dist, tiles_m, tiles_n);
+  const float* T = (const float*)theta_all;
+  hipStream_t s = (hipStream_t)stream;
+  u64* h0 = (u64*)hist_level0;
+  if (vec && sym) launch_distance<true, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
+  else if (vec) launch_distance<true, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
+  else if (sym) launch_distance<false, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
+  else launch_distance<false, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
   LAUNCH_CHECK("k_distance");
   return STEIN_OK;
 }
@@ -742,23 +844,31 @@ extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total,
   return STEIN_OK;
 }
 
+template <int LEVEL>
+static void launch_hist(bool sym, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
+                        const SelState* st, u64* h) {
+  if (sym)
+    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h);
+  else
+    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h);
+}
+
 extern "C" int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
-                                      const void* select_state, void* hist, void* stream) {
+                                      const void* select_state, void* hist, int flags, void* stream) {
   if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
   if (ld_dist < n || (ld_dist & 3) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape");
+  const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
+  if (sym && n_local != n) return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs a square block");
   const long segs = (n + 1023) / 1024;
   long units = (long)n_local * segs;
   const int blocks = (int)(units < 2048 ? units : 2048);
   u64* h = (u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
   const SelState* st = (const SelState*)select_state;
   hipStream_t s = (hipStream_t)stream;
-  if (level == 0)
-    hipLaunchKernelGGL(k_hist<0>, dim3(blocks), dim3(256), 0, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
-  else if (level == 1)
-    hipLaunchKernelGGL(k_hist<1>, dim3(blocks), dim3(256), 0, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
-  else
-    hipLaunchKernelGGL(k_hist<2>, dim3(blocks), dim3(256), 0, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  if (level == 0) launch_hist<0>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  else if (level == 1) launch_hist<1>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  else launch_hist<2>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
   LAUNCH_CHECK("k_hist");
   return STEIN_OK;
 }
@@ -873,11 +983,14 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   float* D = (float*)(ws + L.off[STEIN_WS_DIST]);
   void* hist = ws + L.off[STEIN_WS_HIST];
   void* sel = ws + L.off[STEIN_WS_SELECT];
+  // single rank: the block is the whole symmetric matrix -> upper-triangle distance pass with mirrored stores,
+  // level-0 histogram taken in its epilogue, levels 1-2 read the upper triangle only
+  const int sf = STEIN_STAGE_SYMMETRIC;
   if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
-  if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, stream))) return rc;
   if ((rc = stein_median_begin(hist, sel, n * n, stream))) return rc;
+  if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, sf, stream))) return rc;
   for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv) {
-    if ((rc = stein_median_hist_pass(D, L.ld_dist, n_local, n, lv, sel, hist, stream))) return rc;
+    if (lv > 0 && (rc = stein_median_hist_pass(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream))) return rc;
     if ((rc = stein_median_resolve(hist, lv, n, sel, h2_out, nullptr, stream))) return rc;
   }
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;

@@ -47,14 +47,16 @@ class HipStages:
     def rownorms(self, T, n, d, r):
         _lib.call("stein_rownorms", _ptr(T), n, d, _lib.F32, _ptr(r), _stream(T))
 
-    def distance_block(self, T, r, n, d, row0, n_local, D, ld):
-        _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _lib.F32, _ptr(D), ld, _stream(T))
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False):
+        _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _lib.F32, _ptr(D), ld, _ptr(hist0),
+                  _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
 
     def median_begin(self, hist, sel, total):
         _lib.call("stein_median_begin", _ptr(hist), _ptr(sel), total, _stream(hist))
 
-    def median_hist_pass(self, D, ld, n_local, n, level, sel, hist):
-        _lib.call("stein_median_hist_pass", _ptr(D), ld, n_local, n, level, _ptr(sel), _ptr(hist), _stream(D))
+    def median_hist_pass(self, D, ld, n_local, n, level, sel, hist, symmetric=False):
+        _lib.call("stein_median_hist_pass", _ptr(D), ld, n_local, n, level, _ptr(sel), _ptr(hist),
+                  _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(D))
 
     def median_resolve(self, hist, level, n, sel, h2, median):
         _lib.call("stein_median_resolve", _ptr(hist), level, n, _ptr(sel), _ptr(h2), _ptr(median), _stream(hist))
@@ -173,12 +175,16 @@ class SvgdEngine:
         D, ld, hist, sel = self.dist, self.ld_dist, self.hist, self.select_state
         mark("rownorms")
         st.rownorms(T_all, n, d, self.rownorm)
-        mark("distance")
-        st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld)
-        mark("median")
+        # the distance pass fills the level-0 histogram from its accumulators; a single rank holds the whole
+        # symmetric matrix and only computes / counts its upper triangle
+        sym = self.world == 1
         st.median_begin(hist, sel, n * n)
+        mark("distance")
+        st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld, hist0=hist[0], symmetric=sym)
+        mark("median")
         for level in range(_lib.HIST_LEVELS):
-            st.median_hist_pass(D, ld, nl, n, level, sel, hist)
+            if level > 0:
+                st.median_hist_pass(D, ld, nl, n, level, sel, hist, symmetric=sym)
             if self.world > 1:
                 dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
             st.median_resolve(hist, level, n, sel, self.h2, self.median)

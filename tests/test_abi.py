@@ -55,7 +55,7 @@ def test_null_pointers_are_refused_before_any_launch():
     null = ctypes.c_void_p(0)
     assert lib.stein_rownorms(null, 8, 8, _lib.F32, null, null) == _lib.E_BADARG
     assert b"NULL" in lib.stein_last_error()
-    assert lib.stein_median_hist_pass(null, 8, 8, 8, 0, null, null, null) == _lib.E_BADARG
+    assert lib.stein_median_hist_pass(null, 8, 8, 8, 0, null, null, 0, null) == _lib.E_BADARG
     assert lib.stein_apply_adam(null, null, null, null, 8, _lib.F32, null, 1.0, 10.0, 1e-3, 0.9, 0.999, 1e-8, 1,
                                 null, null) == _lib.E_BADARG
     total = ctypes.c_size_t(0)

@@ -79,7 +79,7 @@ def test_stages_match_oracle(cuda, n, d):
     assert np.linalg.norm(phi - ref32["phi"]) <= 2e-5 * np.linalg.norm(ref32["phi"])
 
 
-@pytest.mark.parametrize("n,d", [(100, 10), (512, 48), (1536, 256)])
+@pytest.mark.parametrize("n,d", [(7, 3), (100, 10), (129, 5), (512, 48), (1000, 130), (1536, 256)])
 def test_fused_equals_staged(cuda, n, d):
     T64, G64 = _inputs(n, d, seed=3)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
@@ -87,10 +87,19 @@ def test_fused_equals_staged(cuda, n, d):
     eng = SvgdEngine(n, d, device=cuda)
     _staged(eng, T, G)
     phi_staged, h2_staged, sq_staged = eng.phi.clone(), eng.h2.clone(), eng.sqnorm.clone()
-    eng.phi.zero_(); eng.h2.zero_(); eng.sqnorm.zero_()
+    D_staged, hist_staged = eng.dist[:, :n].clone(), eng.hist.clone()
+    eng.phi.zero_(); eng.h2.zero_(); eng.sqnorm.zero_(); eng.dist.fill_(float("nan"))
+    # the fused call runs the symmetric variant (upper-triangle tiles mirrored, level-0 histogram from the
+    # distance epilogue, levels 1-2 over the upper triangle with weight 2): every bit must agree
     eng.compute_phi(T, G)
     torch.cuda.synchronize()
+    assert torch.equal(eng.dist[:, :n], D_staged)
+    assert torch.equal(eng.hist, hist_staged)
     assert torch.equal(eng.phi, phi_staged) and torch.equal(eng.h2, h2_staged) and torch.equal(eng.sqnorm, sq_staged)
+    # the marked (bench) path = staged calls with the same symmetric flags
+    eng.phi.zero_()
+    eng.compute_phi(T, G, mark=lambda label: None)
+    assert torch.equal(eng.phi, phi_staged) and torch.equal(eng.hist, hist_staged)
     # determinism: same inputs, same bits
     again = eng.compute_phi(T, G).clone()
     assert torch.equal(again, phi_staged)
