@@ -174,13 +174,19 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
                              "--nproc-per-node %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("STEIN_REHEARSAL_ONE_GPU"):   # rehearse the multi-rank path with all ranks on one card
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist, group = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("STEIN_DIST_BACKEND", "nccl")   # RCCL; "gloo" only for one-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
         group = dist.group.WORLD
 
     import __graft_entry__ as ge
