@@ -44,7 +44,10 @@ enum { STEIN_F32 = 0, STEIN_BF16 = 1, STEIN_F64 = 2 };
 
 /* flags for stein_svgd_phi / stein_workspace_bytes */
 enum {
-  STEIN_FLAG_NONE = 0
+  STEIN_FLAG_NONE = 0,
+  STEIN_FLAG_X3 = 1 /* run both GEMMs on the bf16 matrix cores with every fp32 operand split into three bf16 terms
+                       (hi + mid + lo, six products per pair: fp32-level accuracy at ~2.7x the fp32-MFMA rate).
+                       Adds the PLANES section to the workspace. */
 };
 /* flags for the staged distance / histogram calls */
 enum {
@@ -63,7 +66,7 @@ enum {
   STEIN_WS_PART_T = 5,   /* float  [split][n_local][d]      partial K.theta                       */
   STEIN_WS_PART_RS = 6,  /* float  [split][n_local]         partial rowsum(K)                     */
   STEIN_WS_SQPART = 7,   /* double [sq_blocks]              per-block partial |phi|^2             */
-  STEIN_WS_BF16 = 8,     /* bf16 staging copies (bf16 mode only)                                  */
+  STEIN_WS_PLANES = 8,   /* split-bf16 operand planes (STEIN_FLAG_X3 only; empty otherwise), always last  */
   STEIN_WS_NSECTIONS = 9
 };
 /* extra[] entries reported by stein_workspace_layout */
@@ -110,7 +113,16 @@ int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float
  * stein_median_hist_pass(level 0).  flags: 0 or STEIN_STAGE_SYMMETRIC. */
 int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d,
                          int64_t row0, int64_t n_local, int dtype,
-                         float* dist_out, int64_t ld_dist, void* hist_level0, int flags, void* stream);
+                         float* dist_out, int64_t ld_dist, void* hist_level0, const void* x3_planes, int flags,
+                         void* stream);
+
+/* Split-bf16 mode (STEIN_FLAG_X3), staged form: fills the PLANES section (x3_planes = workspace +
+ * offsets[STEIN_WS_PLANES], planes_bytes = total - offsets[STEIN_WS_PLANES]) with the three bf16 terms of every
+ * entry of theta (row-major and transposed) and of the score (transposed).  Passing the same pointer as
+ * `x3_planes` to stein_distance_block / stein_contract_partial / stein_kernel_contract selects the bf16-MFMA
+ * kernels there; NULL selects the fp32-MFMA kernels. */
+int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, void* x3_planes,
+                     size_t planes_bytes, void* stream);
 
 /* Exact median of all n*n distances by 3-level radix select on the fp32 bit pattern.
  * compute_median.py:4-16 (tf.nn.top_k of n^2//2+1 values; even count -> mean of the two middle).
@@ -138,17 +150,19 @@ int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int
 int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
                           int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
-                          void* workspace, size_t ws_bytes, void* stream);
+                          const void* x3_planes, void* workspace, size_t ws_bytes, void* stream);
 
 /* The two halves of stein_kernel_contract, exposed so a harness can time the MFMA kernel on its own:
  *   partial : k_phi_partial only (fills the PART_G / PART_T / PART_RS workspace sections)
  *   finish  : sums the split partials, forms phi (and dK), reduces |phi|^2 */
 int stein_contract_partial(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
                            int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
-                           const float* h2_dev, void* workspace, size_t ws_bytes, void* stream);
+                           const float* h2_dev, const void* x3_planes, void* workspace, size_t ws_bytes,
+                           void* stream);
 int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
-                          void* workspace, size_t ws_bytes, void* stream);
+                          void* workspace, size_t ws_bytes, int flags /* same STEIN_FLAG_* as the partial */,
+                          void* stream);
 
 /* ---- optimizer apply ---------------------------------------------------------------------------
  * Fuses the norm clip  phi *= 10 / max(10, |phi|_F)  (abstract_stein_sampler.py:125), the optimizer

@@ -91,14 +91,14 @@ class NumpyStages:
         self._st = None
         self._partial = None
 
-    def workspace_layout(self, n_local, n, d):
+    def workspace_layout(self, n_local, n, d, flags=0):
         return self._layout(n_local, n, d)
 
     def rownorms(self, T, n, d, r):
         t = T.numpy()
         r.numpy()[:] = (t * t).sum(axis=1)
 
-    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False):
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None):
         t, rr = T.numpy(), r.numpy()
         blk = rr[row0:row0 + n_local, None] + rr[None, :] - np.float32(2) * (t[row0:row0 + n_local] @ t.T)
         D.numpy()[:, :n] = blk
@@ -118,11 +118,11 @@ class NumpyStages:
             h2.numpy()[0] = self._st.h2
             median.numpy()[0] = self._st.median
 
-    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws):
+    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None):
         K = np.exp(-D.numpy()[:n_local, :n] / h2.numpy()[0] / np.float32(2)).astype(np.float64)
         self._partial = (K @ G.numpy().astype(np.float64), K @ T.numpy().astype(np.float64), K.sum(axis=1))
 
-    def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+    def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, flags=0):
         kg, kt, rs = self._partial
         th = T.numpy()[row0:row0 + n_local].astype(np.float64)
         dk = (rs[:, None] * th - kt) / float(h2.numpy()[0])
@@ -132,7 +132,7 @@ class NumpyStages:
         if dK is not None:
             dK.numpy()[:] = dk
 
-    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
         self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws)
         self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws)
 

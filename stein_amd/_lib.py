@@ -13,12 +13,13 @@ LIB_PATH = os.path.join(_HERE, "libsteinhip.so")
 OK, E_BADARG, E_SHAPE, E_WORKSPACE, E_HIP, E_RCCL, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 F32, BF16, F64 = 0, 1, 2
 
-WS_ROWNORM, WS_DIST, WS_HIST, WS_SELECT, WS_PART_G, WS_PART_T, WS_PART_RS, WS_SQPART, WS_BF16 = range(9)
+WS_ROWNORM, WS_DIST, WS_HIST, WS_SELECT, WS_PART_G, WS_PART_T, WS_PART_RS, WS_SQPART, WS_PLANES = range(9)
 WS_NSECTIONS = 9
 WSX_LD_DIST, WSX_SPLIT, WSX_SQ_BLOCKS, WSX_HIST_BINS = range(4)
 WSX_N = 4
 HIST_BINS, HIST_LEVELS = 2048, 3
 STAGE_SYMMETRIC = 1
+FLAG_X3 = 1
 
 _c = ctypes
 _vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.c_size_t
@@ -29,14 +30,15 @@ _SIGNATURES = {
     "stein_workspace_layout": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz), _c.POINTER(_i64)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_rownorms": [_vp, _i64, _i64, _int, _vp, _vp],
-    "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _int, _vp],
+    "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _int, _vp],
+    "stein_x3_prepare": [_vp, _vp, _i64, _i64, _vp, _sz, _vp],
     "stein_median_begin": [_vp, _vp, _i64, _vp],
     "stein_median_hist_pass": [_vp, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp],
     "stein_median_resolve": [_vp, _int, _i64, _vp, _vp, _vp, _vp],
     "stein_kernel_matrix": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp],
-    "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "stein_contract_partial": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp],
-    "stein_contract_finish": [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "stein_contract_partial": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp],
+    "stein_contract_finish": [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_apply_adagrad": [_vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp],
     "stein_apply_adam": [_vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],
     "stein_cast_f64_to_f32": [_vp, _vp, _i64, _vp],

@@ -1,0 +1,263 @@
+// stein_common.h -- device helpers shared by the fp32-MFMA kernels (steinhip.hip) and the split-bf16
+// kernels (stein_x3.hip): tile geometry, tile-id mapping, radix-select keys/state, and the two epilogues.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "steinhip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- error plumbing (defined in steinhip.hip) ---------------------------------------------------
+int stein_fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return stein_fail(STEIN_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define LAUNCH_CHECK(name)                                                                           \
+  do {                                                                                               \
+    hipError_t e_ = hipGetLastError();                                                               \
+    if (e_ != hipSuccess) return stein_fail(STEIN_E_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- tiling constants shared by the MFMA kernels ---------------------------------------------------
+constexpr int BM = 128;        // rows of the output tile per workgroup
+constexpr int BN = 128;        // columns of the output tile per workgroup
+constexpr int BK = 32;         // contraction depth staged per iteration
+constexpr int NTHREADS = 256;  // 4 waves, arranged 2x2, each owning a 64x64 sub-tile = 2x2 MFMA 32x32 tiles
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one contiguous range of
+// logical tile ids so neighbouring tiles (which share operand panels) hit the same L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// logical tile id -> (tile_m, tile_n) of the distance pass.
+//   SYM: upper triangle, row by row: row tm holds tiles (tm, tm..t-1); first id of row tm = tm*t - tm(tm-1)/2
+//   else: grouped order, 8 row tiles x all column tiles, inside each XCD's contiguous id range
+template <bool SYM>
+__device__ __forceinline__ void distance_tile(int logical, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  if (SYM) {
+    const int t_ = tiles_n;
+    int tm = (int)(((2.0 * t_ + 1.0) - sqrt((2.0 * t_ + 1.0) * (2.0 * t_ + 1.0) - 8.0 * (double)logical)) * 0.5);
+    tm = max(0, min(tm, t_ - 1));
+    while (tm > 0 && (long)tm * t_ - (long)tm * (tm - 1) / 2 > logical) --tm;
+    while ((long)(tm + 1) * t_ - (long)(tm + 1) * tm / 2 <= logical) ++tm;
+    tile_m = tm;
+    tile_n = tm + (logical - (int)((long)tm * t_ - (long)tm * (tm - 1) / 2));
+  } else {
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = logical / per_group;
+    const int first_m = g * GROUP;
+    const int gsize = min(tiles_m - first_m, GROUP);
+    const int in_g = logical - g * per_group;
+    tile_m = first_m + in_g % gsize;
+    tile_n = in_g / gsize;
+  }
+}
+
+// ---- radix select: keys and state -----------------------------------------------------------------
+struct SelState {
+  u64 rank[2];     // remaining 0-based ascending rank of each target inside its current prefix
+  u32 prefix[2];   // key bits fixed so far
+  u32 diverged;    // the two targets no longer share a prefix
+  u32 even;        // n*n even -> median is the mean of the two targets
+  float median;
+  float h2;
+  float lo, hi;    // the two order statistics
+  u32 pad[4];
+};
+static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
+
+__device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
+  const u32 u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(u32 k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// Add `valid` lanes' digits to an LDS histogram.  Distances cluster (a handful of top-level bins hold
+// everything), so the wave first merges lanes that share the leader's digit into one atomic, twice,
+// and only the stragglers fall back to per-lane atomics.
+// `w` is the (wave-uniform) weight of every valid lane: 2 when an upper-triangle entry also stands for its mirror.
+__device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane, u32 w = 1u) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const u64 act = __ballot(valid);
+    if (act == 0ull) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const u32 ld = (u32)__builtin_amdgcn_readlane((int)digit, leader);
+    const bool same = valid && digit == ld;
+    const u64 m = __ballot(same);
+    if (lane == leader) atomicAdd(&h[ld], (u32)__popcll(m) * w);
+    valid = valid && !same;
+  }
+  if (valid) atomicAdd(&h[digit], w);
+}
+
+// ---- epilogue of the distance pass ---------------------------------------------------------------------
+// acc[i][j] are the four 32x32 MFMA accumulators of this wave's 64x64 sub-tile of S = T T^T
+// (C/D map: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)).  Writes D = r_i + r_j - 2 S, the
+// mirrored copy of an off-diagonal tile when SYM, and (hist0 != NULL) the level-0 radix-select histogram.
+//
+// SYM: entries strictly below the diagonal are never taken from the accumulators -- every entry above it is stored
+// twice (itself and its mirror image) and counted twice, so D is exactly symmetric whatever the product order
+// inside the MFMA chain was.  Off-diagonal tiles mirror with 16-byte stores, diagonal tiles element by element.
+//
+// Level-0 counting: the 64 values of a thread fall into a few neighbouring digits, so each thread keeps eight
+// 8-bit counters (one 64-bit register, <= 128 per slot) for the window [base, base+7] around its wave's first digit
+// and touches the LDS histogram once per window slot at the end; values outside the window go straight to LDS.
+//
+// The body is instantiated three times -- interior tile (no predicates), edge tile, diagonal tile -- and the
+// workgroup picks one with a single uniform branch.
+template <bool MIRROR, bool PRED, bool DIAG, bool HIST>
+__device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
+                                                       float* __restrict__ D, int n, int row0, int n_local, long ldD,
+                                                       int tile_m, int brow0, u32 base, u64& packed) {
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wy = wid >> 1, wx = wid & 1;
+  const int l31 = lane & 31, h4 = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = brow0 + wx * 64 + j * 32 + l31;
+      const bool cok = !PRED || col < n;
+      const float rj = cok ? r[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int lrow4 = tile_m * BM + wy * 64 + i * 32 + 8 * g + h4;  // first of 4 consecutive rows (e & 3)
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lrow = lrow4 + q;
+          const bool rok = !PRED || lrow < n_local;
+          const float ri = rok ? r[row0 + lrow] : 0.f;
+          v[q] = (ri + rj) - 2.f * acc[i][j][4 * g + q];
+          u32 w = MIRROR ? 2u : 1u;
+          if (DIAG) w = lrow < col ? 2u : (lrow == col ? 1u : 0u);
+          if (PRED && !(cok && rok)) w = 0u;
+          if ((!PRED && !DIAG) || w) {
+            D[(size_t)lrow * ldD + col] = v[q];
+            if (DIAG && w == 2u) D[(size_t)col * ldD + lrow] = v[q];
+            if (HIST) {
+              const u32 dg = f32_key(v[q]) >> 21;
+              const u32 off = dg - base;
+              if (off < 8u) packed += (u64)w << (8u * off);
+              else atomicAdd(&hl[dg], w);
+            }
+          }
+        }
+        // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (16-byte aligned: ldD % 64 == 0,
+        // lrow4 % 4 == 0).  Entries past n land in the row's padding, which no later stage reads.
+        if (MIRROR && cok && (!PRED || lrow4 < n_local))
+          *reinterpret_cast<float4*>(D + (size_t)col * ldD + lrow4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// `hl` is >= 8 KB of LDS that the caller no longer needs (all waves must be past their last LDS read).
+template <bool SYM>
+__device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
+                                                  float* __restrict__ D, int n, int row0, int n_local, long ldD,
+                                                  int tile_m, int tile_n, u64* __restrict__ hist0) {
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wy = wid >> 1, wx = wid & 1;
+  const int brow0 = tile_n * BN;
+  u64 packed = 0ull;
+  u32 base = 0u;
+  if (hist0) {
+    for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
+    __syncthreads();
+    const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - 2.f * acc[0][0][0];
+    base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
+    base = base < 3u ? 0u : base - 3u;  // window start
+  }
+  const bool diag = SYM && tile_m == tile_n;
+  const bool edge = brow0 + BN > n || tile_m * BM + BM > n_local;
+#define STEIN_EPI(MIRROR, PRED, DIAG)                                                                                  \
+  do {                                                                                                                 \
+    if (hist0) distance_epilogue_body<MIRROR, PRED, DIAG, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,  \
+                                                                base, packed);                                        \
+    else distance_epilogue_body<MIRROR, PRED, DIAG, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0, base, \
+                                                           packed);                                                   \
+  } while (0)
+  if (diag) STEIN_EPI(false, true, true);
+  else if (edge) STEIN_EPI(SYM, true, false);
+  else STEIN_EPI(SYM, false, false);
+#undef STEIN_EPI
+  if (hist0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      u32 c = (u32)(packed >> (8 * k)) & 255u;  // wave-sum of slot k, then one LDS atomic per wave
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if (lane == 0 && c) atomicAdd(&hl[base + k], c);
+    }
+    __syncthreads();
+    for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS)
+      if (hl[b]) atomicAdd(&hist0[b], (u64)hl[b]);
+  }
+}
+
+// ---- epilogue of the contraction: partial O tile + partial rowsum ----------------------------------
+// rs[p] is this thread's running sum of P over the rows lr + 32p it staged (8 consecutive lanes share a row).
+__device__ __forceinline__ void phi_epilogue(const f32x16 (&acc)[2][2], const float (&rs)[4], float* __restrict__ Oz,
+                                             float* __restrict__ RSz, int d, int n_local, int i0, int c0,
+                                             bool write_rowsum) {
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wy = wid >> 1, wx = wid & 1;
+  const int l31 = lane & 31, h4 = (lane >> 5) * 4;
+  const int lr = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = c0 + wx * 64 + j * 32 + l31;
+      if (col >= d) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + h4;
+        if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e];
+      }
+    }
+  }
+  if (write_rowsum) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float s = rs[p];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const int row = i0 + lr + 32 * p;
+      if ((t & 7) == 0 && row < n_local) RSz[row] = s;
+    }
+  }
+}
+
+// ---- host-side layout (shared by both translation units) -----------------------------------------------
+struct SteinLayout {
+  size_t off[STEIN_WS_NSECTIONS];
+  size_t total;
+  int64_t ld_dist, split, sq_blocks, jchunk, tiles_m, cblocks;
+  // split-bf16 planes (flags & STEIN_FLAG_X3): ushort [3][rows][k] each
+  int64_t x3_rows, x3_dk;   // row-major theta planes: x3_rows x x3_dk  (distance operands)
+  int64_t x3_dc, x3_nk;     // transposed planes of theta and of the score: x3_dc x x3_nk  (contraction B operand)
+  size_t x3_t3, x3_tt3, x3_gt3;  // byte offsets inside the PLANES section
+};
+int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, SteinLayout* L);

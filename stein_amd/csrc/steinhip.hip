@@ -23,59 +23,27 @@
 #include <string.h>
 #include <math.h>
 
-#include "steinhip.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned long long u64;
-typedef unsigned int u32;
+#include "stein_common.h"
+#include "stein_x3.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
+int stein_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-
-#define HIP_TRY(expr)                                                                    \
-  do {                                                                                   \
-    hipError_t e_ = (expr);                                                              \
-    if (e_ != hipSuccess) return fail(STEIN_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-#define LAUNCH_CHECK(name)                                                               \
-  do {                                                                                   \
-    hipError_t e_ = hipGetLastError();                                                   \
-    if (e_ != hipSuccess) return fail(STEIN_E_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
-  } while (0)
+#define fail stein_fail
 
 extern "C" int stein_version(void) { return STEIN_VERSION; }
 extern "C" const char* stein_last_error(void) { return g_err; }
 
-// ------------------------------------------------------------------------------------------------
-// tiling constants shared by the two MFMA kernels
-// ------------------------------------------------------------------------------------------------
-constexpr int BM = 128;        // rows of the output tile per workgroup
-constexpr int BN = 128;        // columns of the output tile per workgroup
-constexpr int BK = 32;         // contraction depth staged per iteration
-constexpr int LDK = BK + 4;    // LDS row stride (floats) of a [rows][k] tile: +16 B keeps ds_read_b128 conflict-free
-constexpr int NTHREADS = 256;  // 4 waves, arranged 2x2, each owning a 64x64 sub-tile = 2x2 MFMA 32x32 tiles
-
-// Blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one contiguous range of
-// logical tile ids so neighbouring tiles (which share operand panels) hit the same L2.  Speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
-__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
+constexpr int LDK = BK + 4;    // LDS row stride (floats) of a [rows][k] fp32 tile: +16 B keeps ds_read_b128 conflict-free
 
 // Row-of-k tile loader: rows `rbase + lr + 32p`, k range [k0 + lc, +4).  VEC requires d % 4 == 0.
 template <bool VEC>
@@ -123,28 +91,8 @@ __global__ __launch_bounds__(256) void k_rownorms(const float* __restrict__ T, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// radix select: keys, state, histogram pass, resolve
+// radix select (keys, state and hist_add live in stein_common.h)
 // ------------------------------------------------------------------------------------------------
-struct SelState {
-  u64 rank[2];     // remaining 0-based ascending rank of each target inside its current prefix
-  u32 prefix[2];   // key bits fixed so far
-  u32 diverged;    // the two targets no longer share a prefix
-  u32 even;        // n*n even -> median is the mean of the two targets
-  float median;
-  float h2;
-  float lo, hi;    // the two order statistics
-  u32 pad[4];
-};
-static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
-
-__device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
-  const u32 u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(u32 k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
 __global__ void k_sel_init(SelState* st, u64 total) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const u32 even = (total & 1ull) ? 0u : 1u;
@@ -155,25 +103,6 @@ __global__ void k_sel_init(SelState* st, u64 total) {
     st->even = even;
     st->median = st->h2 = st->lo = st->hi = 0.f;
   }
-}
-
-// Add `valid` lanes' digits to an LDS histogram.  Distances cluster (a handful of top-level bins hold
-// everything), so the wave first merges lanes that share the leader's digit into one atomic, twice,
-// and only the stragglers fall back to per-lane atomics.
-// `w` is the (wave-uniform) weight of every valid lane: 2 when an upper-triangle entry also stands for its mirror.
-__device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane, u32 w = 1u) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const u64 act = __ballot(valid);
-    if (act == 0ull) return;
-    const int leader = __ffsll((long long)act) - 1;
-    const u32 ld = (u32)__builtin_amdgcn_readlane((int)digit, leader);
-    const bool same = valid && digit == ld;
-    const u64 m = __ballot(same);
-    if (lane == leader) atomicAdd(&h[ld], (u32)__popcll(m) * w);
-    valid = valid && !same;
-  }
-  if (valid) atomicAdd(&h[digit], w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,28 +124,8 @@ __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tile_m, tile_n;
-  if (SYM) {
-    // upper triangle, row by row: row tm holds tiles (tm, tm..t-1); first id of row tm = tm*t - tm(tm-1)/2
-    const int t_ = tiles_n;
-    int tm = (int)(((2.0 * t_ + 1.0) - sqrt((2.0 * t_ + 1.0) * (2.0 * t_ + 1.0) - 8.0 * (double)logical)) * 0.5);
-    tm = max(0, min(tm, t_ - 1));
-    while (tm > 0 && (long)tm * t_ - (long)tm * (tm - 1) / 2 > logical) --tm;
-    while ((long)(tm + 1) * t_ - (long)(tm + 1) * tm / 2 <= logical) ++tm;
-    tile_m = tm;
-    tile_n = tm + (logical - (int)((long)tm * t_ - (long)tm * (tm - 1) / 2));
-  } else {
-    // grouped tile order inside each XCD's contiguous range: 8 row tiles x all column tiles
-    constexpr int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int g = logical / per_group;
-    const int first_m = g * GROUP;
-    const int gsize = min(tiles_m - first_m, GROUP);
-    const int in_g = logical - g * per_group;
-    tile_m = first_m + in_g % gsize;
-    tile_n = in_g / gsize;
-  }
+  distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n);
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
@@ -264,69 +173,8 @@ __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__
     __syncthreads();
   }
 
-  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-  u32* hl = reinterpret_cast<u32*>(smem);  // the staging tiles are dead: reuse 8 KB as the level-0 histogram
-  if (hist0) {
-    for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
-    __syncthreads();
-  }
-  const bool mirror = SYM && tile_m != tile_n;
-  const u32 weight = mirror ? 2u : 1u;
-  // Level-0 counting: the 64 values of a thread fall into a few neighbouring digits, so each thread keeps eight
-  // 8-bit counters (one 64-bit register) for the window [base-3, base+4] around its wave's first digit and touches
-  // the LDS histogram only once per window slot at the end; values outside the window go straight to LDS.
-  u64 packed = 0ull;
-  u32 base = 0u;
-  if (hist0) {
-    const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - 2.f * acc[0][0][0];
-    base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
-    base = base < 3u ? 0u : base - 3u;  // window start
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = brow0 + wx * 64 + j * 32 + l31;
-      const bool cok = col < n;
-      const float rj = cok ? r[col] : 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int lrow4 = tile_m * BM + wy * 64 + i * 32 + 8 * g + h4;  // first of 4 consecutive rows (e & 3)
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int lrow = lrow4 + q;
-          const bool ok = cok && lrow < n_local;
-          const float ri = lrow < n_local ? r[row0 + lrow] : 0.f;
-          v[q] = (ri + rj) - 2.f * acc[i][j][4 * g + q];
-          if (ok) D[(size_t)lrow * ldD + col] = v[q];
-          if (hist0 && ok) {
-            const u32 dg = f32_key(v[q]) >> 21;
-            const u32 off = dg - base;
-            if (off < 8u) packed += 1ull << (8u * off);
-            else atomicAdd(&hl[dg], weight);
-          }
-        }
-        // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (16-byte aligned: ldD % 64 == 0,
-        // lrow4 % 4 == 0).  Entries past n land in the row's padding, which no later stage reads.
-        if (mirror && cok && lrow4 < n_local)
-          *reinterpret_cast<float4*>(D + (size_t)col * ldD + lrow4) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
-  if (hist0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      // wave-sum of slot k, then one LDS atomic per wave
-      u32 c = (u32)(packed >> (8 * k)) & 255u;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-      if (lane == 0 && c) atomicAdd(&hl[base + k], c * weight);
-    }
-    __syncthreads();
-    for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS)
-      if (hl[b]) atomicAdd(&hist0[b], (u64)hl[b]);
-  }
+  // the staging tiles are dead (every wave is past the loop's last barrier): 8 KB of them hold the level-0 histogram
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,33 +413,7 @@ __global__ __launch_bounds__(NTHREADS) void k_phi_partial(const float* __restric
     __syncthreads();
   }
 
-  // partial O tile
-  float* Oz = O + (size_t)z * n_local * d;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = c0 + wx * 64 + j * 32 + l31;
-      if (col >= d) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = i0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + h4;
-        if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e];
-      }
-    }
-  }
-  // rowsum: the 8 threads of a row are 8 consecutive lanes
-  if (cb == 0) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float s = rs[p];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const int row = i0 + lr + 32 * p;
-      if ((t & 7) == 0 && row < n_local) RS[(size_t)z * n_local + row] = s;
-    }
-  }
+  phi_epilogue(acc, rs, O + (size_t)z * n_local * d, RS + (size_t)z * n_local, d, n_local, i0, c0, cb == 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -697,21 +519,14 @@ __global__ __launch_bounds__(256) void k_cast_f32_bf16(const float* __restrict__
 // ================================================================================================
 // host side
 // ================================================================================================
-namespace {
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct Layout {
-  size_t off[STEIN_WS_NSECTIONS];
-  size_t total;
-  int64_t ld_dist, split, sq_blocks, jchunk, tiles_m, cblocks;
-};
-
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-int make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, Layout* L) {
+int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, SteinLayout* L) {
   if (n < 2) return fail(STEIN_E_BADARG, "n = %lld: the bandwidth divides by ln(n), need n >= 2", (long long)n);
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
+  if (flags & ~STEIN_FLAG_X3) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -720,12 +535,13 @@ int make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, Layout* L) {
   // k_phi_partial runs 3 workgroups per CU (156 registers): 768 resident blocks.  Every block does the same
   // work, so the launch takes ceil(blocks / 768) rounds; pick the j-split that wastes least of the last round
   // (ties -> fewer splits, i.e. less partial traffic), keeping at least 8 j-tiles (256 columns) per split.
+  const double resident = (flags & STEIN_FLAG_X3) ? 512.0 : 768.0;  // the split-bf16 kernel fits 2 workgroups per CU
   int64_t max_split = jt / 8 > 0 ? jt / 8 : 1;
   if (max_split > 16) max_split = 16;
   int64_t split = 1;
   double best = -1.0;
   for (int64_t s = 1; s <= max_split; ++s) {
-    const double rounds = (double)(base * s) / 768.0;
+    const double rounds = (double)(base * s) / resident;
     const double eff = rounds / ceil(rounds) - 0.004 * (double)(s - 1);
     if (eff > best + 1e-9) { best = eff; split = s; }
   }
@@ -752,25 +568,32 @@ int make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, Layout* L) {
   put(STEIN_WS_PART_T, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_RS, (size_t)split * n_local * 4);
   put(STEIN_WS_SQPART, (size_t)sqb * 8);
-  put(STEIN_WS_BF16, dtype == STEIN_BF16 ? (size_t)2 * n * d * 4 : 0);
+  // split-bf16 operand planes: always LAST so the offsets above do not depend on the flag
+  L->x3_rows = (int64_t)align_up((size_t)n, 128) + 128;   // a rank's last row tile may start past roundup(n, 128) - 128
+  L->x3_dk = (int64_t)align_up((size_t)d, 32);
+  L->x3_dc = (int64_t)align_up((size_t)d, 128);
+  L->x3_nk = (int64_t)align_up((size_t)n, 32);
+  const size_t t3 = align_up((size_t)3 * L->x3_rows * L->x3_dk * 2, 256);
+  const size_t tt3 = align_up((size_t)3 * L->x3_dc * L->x3_nk * 2, 256);
+  L->x3_t3 = 0;
+  L->x3_tt3 = t3;
+  L->x3_gt3 = t3 + tt3;
+  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 : 0);
   L->total = at;
   return STEIN_OK;
 }
 
-inline int grid_for(long count, int cap) {
+static inline int grid_for(long count, int cap) {
   long b = (count + 255) / 256;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
 
-}  // namespace
-
 extern "C" int stein_workspace_bytes(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, size_t* out) {
-  (void)flags;
   if (!out) return fail(STEIN_E_BADARG, "out is NULL");
-  Layout L;
-  int rc = make_layout(n_local, n, d, dtype, &L);
+  SteinLayout L;
+  int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
   if (rc) return rc;
   *out = L.total;
   return STEIN_OK;
@@ -778,10 +601,9 @@ extern "C" int stein_workspace_bytes(int64_t n_local, int64_t n, int64_t d, int 
 
 extern "C" int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, size_t* offsets,
                                       int64_t* extra) {
-  (void)flags;
   if (!offsets || !extra) return fail(STEIN_E_BADARG, "NULL output");
-  Layout L;
-  int rc = make_layout(n_local, n, d, dtype, &L);
+  SteinLayout L;
+  int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
   if (rc) return rc;
   for (int i = 0; i < STEIN_WS_NSECTIONS; ++i) offsets[i] = L.off[i];
   extra[STEIN_WSX_LD_DIST] = L.ld_dist;
@@ -789,6 +611,18 @@ extern "C" int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int
   extra[STEIN_WSX_SQ_BLOCKS] = L.sq_blocks;
   extra[STEIN_WSX_HIST_BINS] = STEIN_HIST_BINS;
   return STEIN_OK;
+}
+
+extern "C" int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, void* x3_planes,
+                                size_t planes_bytes, void* stream) {
+  if (!theta_all || !score_all || !x3_planes) return fail(STEIN_E_BADARG, "NULL pointer");
+  SteinLayout L;
+  int rc = stein_make_layout(n, n, d, STEIN_F32, STEIN_FLAG_X3, &L);
+  if (rc) return rc;
+  if (planes_bytes < L.total - L.off[STEIN_WS_PLANES])
+    return fail(STEIN_E_WORKSPACE, "planes buffer %zu < %zu bytes", planes_bytes, L.total - L.off[STEIN_WS_PLANES]);
+  return stein_x3_split((const float*)theta_all, (const float*)score_all, n, d, L, (char*)x3_planes,
+                        (hipStream_t)stream);
 }
 
 extern "C" int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float* r_out, void* stream) {
@@ -811,8 +645,8 @@ static void launch_distance(long nblk, hipStream_t s, const float* T, const floa
 
 extern "C" int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
                                     int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* hist_level0,
-                                    int flags, void* stream) {
-  if (!theta_all || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
+                                    const void* x3_planes, int flags, void* stream) {
+  if ((!theta_all && !x3_planes) || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (n < 1 || d < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   if (ld_dist < n || (ld_dist & 3)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 4");
   if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "distance: dtype %d", dtype);
@@ -822,10 +656,16 @@ extern "C" int stein_distance_block(const void* theta_all, const float* r_all, i
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
   const long nblk = sym ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
   if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
-  const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
-  const float* T = (const float*)theta_all;
   hipStream_t s = (hipStream_t)stream;
   u64* h0 = (u64*)hist_level0;
+  if (x3_planes) {
+    SteinLayout L;
+    int rc = stein_make_layout(n_local, n, d, dtype, STEIN_FLAG_X3, &L);
+    if (rc) return rc;
+    return stein_x3_distance((const char*)x3_planes, L, r_all, dist_out, n, d, row0, n_local, ld_dist, h0, sym, s);
+  }
+  const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
+  const float* T = (const float*)theta_all;
   if (vec && sym) launch_distance<true, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
   else if (vec) launch_distance<true, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
   else if (sym) launch_distance<false, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
@@ -898,15 +738,16 @@ extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n
 
 extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const void* theta_all,
                                       const void* score_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
-                                      int dtype, const float* h2_dev, void* workspace, size_t ws_bytes,
-                                      void* stream) {
-  if (!dist || !theta_all || !score_all || !h2_dev || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
+                                      int dtype, const float* h2_dev, const void* x3_planes, void* workspace,
+                                      size_t ws_bytes, void* stream) {
+  if (!dist || (!x3_planes && (!theta_all || !score_all)) || !h2_dev || !workspace)
+    return fail(STEIN_E_BADARG, "NULL pointer");
   if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
-  Layout L;
-  int rc = make_layout(n_local, n, d, dtype, &L);
+  SteinLayout L;
+  int rc = stein_make_layout(n_local, n, d, dtype, x3_planes ? STEIN_FLAG_X3 : 0, &L);
   if (rc) return rc;
-  if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  if (ws_bytes < L.off[STEIN_WS_PLANES]) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.off[STEIN_WS_PLANES]);
   if (ld_dist != L.ld_dist) return fail(STEIN_E_SHAPE, "ld_dist %lld != %lld", (long long)ld_dist, (long long)L.ld_dist);
   char* ws = (char*)workspace;
   float* OG = (float*)(ws + L.off[STEIN_WS_PART_G]);
@@ -917,6 +758,8 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
   hipStream_t s = (hipStream_t)stream;
   const long nblk = (long)L.tiles_m * 2 * L.cblocks * L.split;
   if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
+  if (x3_planes)
+    return stein_x3_contract_partial(dist, ld_dist, (const char*)x3_planes, L, h2_dev, OG, OT, RS, n, d, n_local, s);
   const bool vec = (d % 4 == 0) && (((uintptr_t)T & 15) == 0) && (((uintptr_t)G & 15) == 0);
   if (vec)
     hipLaunchKernelGGL(k_phi_partial<true>, dim3((unsigned)nblk), dim3(NTHREADS), 0, s, dist, (long)ld_dist, G, T,
@@ -932,14 +775,14 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
 
 extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
                                      int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
-                                     float* dK_out, void* workspace, size_t ws_bytes, void* stream) {
+                                     float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
   if (!theta_all || !h2_dev || !phi_local || !sqnorm_out || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
   if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
-  Layout L;
-  int rc = make_layout(n_local, n, d, dtype, &L);
+  SteinLayout L;
+  int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
   if (rc) return rc;
-  if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  if (ws_bytes < L.off[STEIN_WS_PLANES]) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.off[STEIN_WS_PLANES]);
   char* ws = (char*)workspace;
   const float* OG = (const float*)(ws + L.off[STEIN_WS_PART_G]);
   const float* OT = (const float*)(ws + L.off[STEIN_WS_PART_T]);
@@ -957,24 +800,23 @@ extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d
 extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
                                      int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                                      const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
-                                     void* workspace, size_t ws_bytes, void* stream) {
-  int rc = stein_contract_partial(dist, ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, workspace,
-                                  ws_bytes, stream);
+                                     const void* x3_planes, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = stein_contract_partial(dist, ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, x3_planes,
+                                  workspace, ws_bytes, stream);
   if (rc) return rc;
   return stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
-                               ws_bytes, stream);
+                               ws_bytes, x3_planes ? STEIN_FLAG_X3 : 0, stream);
 }
 
 extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0,
                               int64_t n_local, int dtype, float* phi_local, float* h2_out, double* sqnorm_out,
                               float* K_out, float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
-  (void)flags;
   if (!theta_all || !score_all || !phi_local || !h2_out || !sqnorm_out || !workspace)
     return fail(STEIN_E_BADARG, "NULL pointer");
   if (row0 != 0 || n_local != n)
     return fail(STEIN_E_BADARG, "stein_svgd_phi is the single-rank path (row0 = 0, n_local = n); use the staged calls");
-  Layout L;
-  int rc = make_layout(n_local, n, d, dtype, &L);
+  SteinLayout L;
+  int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
   if (rc) return rc;
   if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "svgd_phi: dtype %d not built yet", dtype);
   if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
@@ -983,19 +825,23 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   float* D = (float*)(ws + L.off[STEIN_WS_DIST]);
   void* hist = ws + L.off[STEIN_WS_HIST];
   void* sel = ws + L.off[STEIN_WS_SELECT];
+  void* planes = (flags & STEIN_FLAG_X3) ? ws + L.off[STEIN_WS_PLANES] : nullptr;
   // single rank: the block is the whole symmetric matrix -> upper-triangle distance pass with mirrored stores,
   // level-0 histogram taken in its epilogue, levels 1-2 read the upper triangle only
   const int sf = STEIN_STAGE_SYMMETRIC;
   if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
+  if (planes && (rc = stein_x3_prepare(theta_all, score_all, n, d, planes, L.total - L.off[STEIN_WS_PLANES], stream)))
+    return rc;
   if ((rc = stein_median_begin(hist, sel, n * n, stream))) return rc;
-  if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, sf, stream))) return rc;
+  if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream)))
+    return rc;
   for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv) {
     if (lv > 0 && (rc = stein_median_hist_pass(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream))) return rc;
     if ((rc = stein_median_resolve(hist, lv, n, sel, h2_out, nullptr, stream))) return rc;
   }
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;
   return stein_kernel_contract(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, phi_local,
-                               sqnorm_out, dK_out, workspace, ws_bytes, stream);
+                               sqnorm_out, dK_out, planes, workspace, ws_bytes, stream);
 }
 
 template <typename S>

@@ -15,6 +15,7 @@ cross a link.  Mirrors the single call at
 stein/samplers/abstract_stein_sampler.py:103-105 (K, dK = kernel_and_grad; phi).
 """
 import ctypes
+import os
 
 import torch
 
@@ -37,19 +38,22 @@ class HipStages:
 
     name = "hip"
 
-    def workspace_layout(self, n_local, n, d):
-        return _lib.workspace_layout(n_local, n, d, _lib.F32, 0)
+    def workspace_layout(self, n_local, n, d, flags=0):
+        return _lib.workspace_layout(n_local, n, d, _lib.F32, flags)
 
-    def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws):
+    def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws, flags=0):
         _lib.call("stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _lib.F32, _ptr(phi), _ptr(h2), _ptr(sqnorm),
-                  _ptr(K), _ptr(dK), _ptr(ws), ws.numel(), 0, _stream(T))
+                  _ptr(K), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
+
+    def x3_prepare(self, T, G, n, d, planes):
+        _lib.call("stein_x3_prepare", _ptr(T), _ptr(G), n, d, _ptr(planes), planes.numel(), _stream(T))
 
     def rownorms(self, T, n, d, r):
         _lib.call("stein_rownorms", _ptr(T), n, d, _lib.F32, _ptr(r), _stream(T))
 
-    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False):
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None):
         _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _lib.F32, _ptr(D), ld, _ptr(hist0),
-                  _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
+                  _ptr(planes), _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
 
     def median_begin(self, hist, sel, total):
         _lib.call("stein_median_begin", _ptr(hist), _ptr(sel), total, _stream(hist))
@@ -64,17 +68,17 @@ class HipStages:
     def kernel_matrix(self, D, ld, n_local, n, h2, K):
         _lib.call("stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
 
-    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws):
+    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None):
         _lib.call("stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _lib.F32, _ptr(h2),
-                  _ptr(ws), ws.numel(), _stream(D))
+                  _ptr(planes), _ptr(ws), ws.numel(), _stream(D))
 
-    def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
+    def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, flags=0):
         _lib.call("stein_contract_finish", _ptr(T), n, d, row0, n_local, _lib.F32, _ptr(h2), _ptr(phi),
-                  _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), _stream(T))
+                  _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
-    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws):
-        self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws)
-        self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws)
+    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
+        self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws, planes)
+        self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, _lib.FLAG_X3 if planes is not None else 0)
 
 
 class SvgdEngine:
@@ -89,8 +93,13 @@ class SvgdEngine:
               (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
     """
 
-    def __init__(self, n, d, device="cuda", group=None, stages=None):
+    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None):
         self.n, self.d = int(n), int(d)
+        # x3: run both GEMMs as split-bf16 (three bf16 terms per fp32 operand) on the bf16 matrix cores
+        if x3 is None:
+            x3 = os.environ.get("STEIN_X3", "0") not in ("0", "", "false")
+        self.x3 = bool(x3)
+        self.flags = _lib.FLAG_X3 if self.x3 else 0
         self.device = torch.device(device)
         self.stages = stages if stages is not None else HipStages()
         self.group = group
@@ -106,7 +115,7 @@ class SvgdEngine:
         self.n_local = self.n // self.world
         self.row0 = self.rank * self.n_local
 
-        total, offs, extra = self.stages.workspace_layout(self.n_local, self.n, self.d)
+        total, offs, extra = self.stages.workspace_layout(self.n_local, self.n, self.d, self.flags)
         self.ws_bytes, self._offs = total, offs
         self.ld_dist, self.split = extra[_lib.WSX_LD_DIST], extra[_lib.WSX_SPLIT]
         dev = self.device
@@ -141,6 +150,14 @@ class SvgdEngine:
     def select_state(self):
         return self._section(_lib.WS_SELECT, 64, torch.uint8)
 
+    @property
+    def planes(self):
+        """split-bf16 operand planes (None unless x3)"""
+        if not self.x3:
+            return None
+        o = self._offs[_lib.WS_PLANES]
+        return self.ws[o:self.ws_bytes]
+
     # ---------------------------------------------------------------------------------------
     def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None, mark=None):
         """theta_local, score_local: [n_local, d] float32 contiguous device tensors (this rank's rows).
@@ -158,7 +175,8 @@ class SvgdEngine:
                 raise ValueError("%s must be a contiguous float32 [%d, %d] tensor, got %s %s" %
                                  (name, nl, d, tuple(t.shape), t.dtype))
         if self.world == 1 and mark is None:
-            st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws)
+            st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
+                        self.flags)
             return self.phi
         if mark is None:
             def mark(label):
@@ -175,12 +193,15 @@ class SvgdEngine:
         D, ld, hist, sel = self.dist, self.ld_dist, self.hist, self.select_state
         mark("rownorms")
         st.rownorms(T_all, n, d, self.rownorm)
+        planes = self.planes
+        if planes is not None:
+            st.x3_prepare(T_all, G_all, n, d, planes)
         # the distance pass fills the level-0 histogram from its accumulators; a single rank holds the whole
         # symmetric matrix and only computes / counts its upper triangle
         sym = self.world == 1
         st.median_begin(hist, sel, n * n)
         mark("distance")
-        st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld, hist0=hist[0], symmetric=sym)
+        st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld, hist0=hist[0], symmetric=sym, planes=planes)
         mark("median")
         for level in range(_lib.HIST_LEVELS):
             if level > 0:
@@ -191,9 +212,9 @@ class SvgdEngine:
         if K_out is not None:
             st.kernel_matrix(D, ld, nl, n, self.h2, K_out)
         mark("contract")
-        st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws)
+        st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws, planes)
         mark("finish")
-        st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws)
+        st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws, self.flags)
         if self.world > 1:
             dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
         mark("end")

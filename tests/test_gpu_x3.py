@@ -1,0 +1,142 @@
+"""GPU: the split-bf16 ("x3") variant of the two GEMMs -- three bf16 terms per fp32 operand, six bf16-MFMA products
+per pair -- must stay inside the same 1e-5 budget as the fp32-MFMA path and agree with it closely."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import svgd_oracle as orc
+from stein_amd import _lib
+from stein_amd.engine import SvgdEngine
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(7, 3), (8, 5), (100, 10), (257, 33), (512, 48), (1000, 130), (1536, 256), (640, 2001)]
+
+
+def _inputs(n, d, seed=0):
+    rng = np.random.default_rng(seed + 1000 * n + d)
+    return rng.normal(size=(n, d)), rng.normal(size=(n, d))
+
+
+def test_split_planes_reconstruct_fp32(cuda):
+    """hi + mid + lo reproduces every fp32 input to <= 2^-24 relative, in both plane layouts."""
+    n, d = 300, 70
+    T64, G64 = _inputs(n, d, 1)
+    T64[0, 0], T64[1, 1], T64[2, 2] = 0.0, 1e-30, -3.0e20
+    T = torch.tensor(T64, dtype=torch.float32, device=cuda)
+    G = torch.tensor(G64, dtype=torch.float32, device=cuda)
+    eng = SvgdEngine(n, d, device=cuda, x3=True)
+    eng.stages.x3_prepare(T, G, n, d, eng.planes)
+    torch.cuda.synchronize()
+    rows, dk = (n + 127) // 128 * 128 + 128, (d + 31) // 32 * 32
+    dc, nk = (d + 127) // 128 * 128, (n + 31) // 32 * 32
+    raw = eng.planes.view(torch.bfloat16)
+    t3 = raw[:3 * rows * dk].view(3, rows, dk).float().sum(0)
+    off = (3 * rows * dk * 2 + 255) // 256 * 256 // 2
+    tt3 = raw[off:off + 3 * dc * nk].view(3, dc, nk).float().sum(0)
+    off2 = off + (3 * dc * nk * 2 + 255) // 256 * 256 // 2
+    gt3 = raw[off2:off2 + 3 * dc * nk].view(3, dc, nk).float().sum(0)
+    tol = 2.0 ** -23
+    assert ((t3[:n, :d] - T).abs() <= tol * T.abs()).all()
+    assert (t3[n:].abs().max() == 0) and (t3[:, d:].abs().max() == 0)          # zero padding
+    assert ((tt3[:d, :n].T - T).abs() <= tol * T.abs()).all()
+    assert ((gt3[:d, :n].T - G).abs() <= tol * G.abs()).all()
+    assert tt3[d:].abs().max() == 0 and tt3[:, n:].abs().max() == 0
+
+
+@pytest.mark.parametrize("n,d", SHAPES)
+def test_x3_matches_oracle_and_fp32_path(cuda, n, d):
+    T64, G64 = _inputs(n, d)
+    T = torch.tensor(T64, dtype=torch.float32, device=cuda)
+    G = torch.tensor(G64, dtype=torch.float32, device=cuda)
+    ref_eng = SvgdEngine(n, d, device=cuda, x3=False)
+    phi32 = ref_eng.compute_phi(T, G).clone()
+    eng = SvgdEngine(n, d, device=cuda, x3=True)
+    dK = torch.empty(n, d, device=cuda)
+    phi = eng.compute_phi(T, G, dK_out=dK).clone()
+    torch.cuda.synchronize()
+
+    D, D32 = eng.dist[:, :n], ref_eng.dist[:, :n]
+    assert torch.equal(D, D.T)                                  # symmetric by construction (mirrored tiles)
+    Dn = D.cpu().numpy()
+    D64 = orc.pairwise_sq_dists(T.cpu().numpy(), np.float64)
+    e_x3, e_32 = np.abs(Dn - D64).max(), np.abs(D32.cpu().numpy() - D64).max()
+    assert e_x3 <= 4e-6 * np.abs(D64).max() and e_x3 <= 3 * e_32 + 1e-7 * np.abs(D64).max(), (e_x3, e_32)
+    med = orc.median_all(Dn)                                    # exact select on the x3 distances themselves
+    assert eng.h2.item() == orc.bandwidth_sq(med, n, np.float32)
+    assert abs(eng.h2.item() - ref_eng.h2.item()) <= 2e-6 * ref_eng.h2.item()
+
+    T32 = T.cpu().numpy().astype(np.float64)
+    ref = orc.svgd_step(T32, G.cpu().numpy().astype(np.float64), orc.AdagradState(), np.float64)
+    p = phi.cpu().numpy().astype(np.float64)
+    err = np.linalg.norm(p - ref["phi"]) / np.linalg.norm(ref["phi"])
+    assert err <= 1e-5, err
+    assert np.all(np.abs(p - ref["phi"]) <= 1e-5 * np.abs(ref["phi"]).max() + 1e-5 * np.abs(ref["phi"]))
+    assert np.linalg.norm(dK.cpu().numpy() - ref["dK"]) <= 1e-5 * np.linalg.norm(ref["dK"])
+    assert ((phi - phi32).norm() / phi32.norm()).item() <= 5e-6
+    assert abs(eng.sqnorm.item() - ref["sqnorm"]) <= 2e-5 * ref["sqnorm"]
+    again = eng.compute_phi(T, G)
+    assert torch.equal(again, phi)                              # deterministic
+
+
+def test_x3_error_is_fp32_level_at_c2_size(cuda):
+    """n=4096, d=128: the x3 error against fp64 must be of the same order as the fp32-MFMA path's."""
+    n, d = 4096, 128
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    T = torch.randn(n, d, generator=gen).to(cuda)
+    G = torch.randn(n, d, generator=gen).to(cuda)
+    T64, G64 = T.double(), G.double()
+    r = (T64 * T64).sum(1)
+    D = r[:, None] + r[None, :] - 2.0 * (T64 @ T64.T)
+    flat = D.flatten().sort().values
+    med = 0.5 * (flat[n * n // 2 - 1] + flat[n * n // 2])
+    h2 = med / np.log(n)
+    K = torch.exp(-D / h2 / 2.0)
+    ref = (K @ G64 + (K.sum(1)[:, None] * T64 - K @ T64) / h2) / n
+    e = {}
+    for x3 in (False, True):
+        eng = SvgdEngine(n, d, device=cuda, x3=x3)
+        phi = eng.compute_phi(T, G).double()
+        e[x3] = ((phi - ref).norm() / ref.norm()).item()
+    assert e[True] <= 1e-5 and e[True] <= 4 * e[False] + 1e-7, e
+
+
+def test_x3_row_blocks_match_full(cuda):
+    """Non-symmetric row blocks (the multi-rank shape) against the symmetric full run: same h2, phi to rounding."""
+    n, d, parts = 1024, 96, 4
+    T64, G64 = _inputs(n, d, 9)
+    T = torch.tensor(T64, dtype=torch.float32, device=cuda)
+    G = torch.tensor(G64, dtype=torch.float32, device=cuda)
+    full = SvgdEngine(n, d, device=cuda, x3=True)
+    phi_full = full.compute_phi(T, G).clone()
+    nl = n // parts
+    total, offs, extra = _lib.workspace_layout(nl, n, d, _lib.F32, _lib.FLAG_X3)
+    ld = extra[_lib.WSX_LD_DIST]
+    st = full.stages
+    hist = torch.zeros(_lib.HIST_LEVELS, 2, _lib.HIST_BINS, dtype=torch.int64, device=cuda)
+    sel = torch.zeros(64, dtype=torch.uint8, device=cuda)
+    h2, med = torch.zeros(1, device=cuda), torch.zeros(1, device=cuda)
+    st.median_begin(hist, sel, n * n)
+    blocks = []
+    for p in range(parts):
+        ws = torch.empty(total, dtype=torch.uint8, device=cuda)
+        planes = ws[offs[_lib.WS_PLANES]:]
+        st.x3_prepare(T, G, n, d, planes)
+        D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nl * ld * 4].view(torch.float32).view(nl, ld)
+        r = torch.empty(n, device=cuda)
+        st.rownorms(T, n, d, r)
+        st.distance_block(T, r, n, d, p * nl, nl, D, ld, hist0=hist[0], planes=planes)
+        blocks.append((ws, planes, D))
+        # direct vs mirrored entries may differ in the last bit (the hi*mid / mid*hi products swap order)
+        assert (D[:, :n] - full.dist[p * nl:(p + 1) * nl, :n]).abs().max().item() <= 1e-6 * full.dist[:, :n].abs().max().item()
+    for lv in range(_lib.HIST_LEVELS):
+        if lv > 0:
+            for ws, planes, D in blocks:
+                st.median_hist_pass(D, ld, nl, n, lv, sel, hist)
+        st.median_resolve(hist, lv, n, sel, h2, med)
+    assert abs(h2.item() - full.h2.item()) <= 1e-6 * full.h2.item()
+    for p, (ws, planes, D) in enumerate(blocks):
+        phi = torch.empty(nl, d, device=cuda)
+        sq = torch.zeros(1, dtype=torch.float64, device=cuda)
+        st.kernel_contract(D, ld, T, G, n, d, p * nl, nl, h2, phi, sq, None, ws, planes)
+        assert ((phi - phi_full[p * nl:(p + 1) * nl]).norm() / phi_full.norm()).item() <= 2e-6
