@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override the workload's particle count (experiments)")
+    ap.add_argument("--d", type=int, default=0, help="override the workload's parameter count (experiments)")
     ap.add_argument("--cpu-rows", type=int, default=16384, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
@@ -192,7 +194,10 @@ def main():
     import __graft_entry__ as ge
     ge.build()
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.n or args.d:
+        wl["n"], wl["d"] = args.n or wl["n"], args.d or wl["d"]
+        wl["name"] = "custom n=%d d=%d fp32" % (wl["n"], wl["d"])
     res = run_workload(torch, dist, args, wl, device, rank, world, group, args.steps, args.warmup)
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
