@@ -1,7 +1,7 @@
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/stein_amd") else os.getcwd())
 from stein_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsteinhip_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPLIB", "libsteinhip_stamps.so"))
 from stein_amd.engine import SvgdEngine
 lib = _lib.load()
 n, d = int(sys.argv[1]), int(sys.argv[2])
@@ -16,7 +16,7 @@ lib.stein_debug_stamps(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 nb = v[7]
 jt = (n + 31) // 32
-names = ["wait_loads", "valu_stage", "barrier1", "prefetch_issue", "mma", "barrier2"]
+names = ["P:produce", "P:issue", "P:barrier", "C:mma", "C:barrier", "-"]
 print("blocks", nb, "split", eng.split, "ktiles/block", jt / eng.split)
 for k, nm in enumerate(names):
     print("%-15s %8.1f ticks per k-tile (100 MHz ticks? s_memtime = shader clock)" % (nm, v[k] / nb / (jt / eng.split)))

@@ -7,29 +7,38 @@
 // pairs are below 2^-24 relative.  bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so
 // the result has fp32-MFMA-level error at 6/16 of its matrix-core time.
 //
-//   k_split3        theta, score -> bf16 planes: theta row-major [3][rows][dk] (distance operands) and
-//                   theta / score transposed [3][dc][nk] (the contraction's B operand, k = particle index)
+//   k_split3        theta, score -> bf16 operand tiles ("planes", layout below)
 //   k_distance_x3   S = T T^T from the planes; shares the fp32 kernel's epilogue (D, mirror, level-0 histogram)
-//   k_phi_x3        P = exp2(c D) is split on the fly into three bf16 planes in LDS; O += P . V^T-planes
+//   k_phi_x3ws      warp-specialised contraction: producer waves build P = exp2(c D) (split on the fly) and stage
+//                   the V tiles, consumer waves only issue MFMAs
 //
-// Both GEMMs are "row x row" products (C[i][c] = sum_k A[i][k] B[c][k]) with k contiguous in memory for both
-// operands, so one LDS image [row][k] (80-byte row stride: conflict-free ds_read_b128) serves A and B fragments:
-// lane l of a 32x32x16 MFMA reads 8 consecutive k at row (l & 31), k offset 8 (l >> 5).
-
-#include "stein_x3.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // staging registers (native vector: stays in VGPRs)
-
-// LDS image of one operand plane: [128 rows][32 bf16] = 64-byte rows with the four 16-byte chunks of a row XOR-swizzled
-// by (row >> 2) & 3.  Conflict-free for all three access shapes (banking rules of MI355X_MICROARCH.md, LDS):
+// Both GEMMs are "row x row" products (C[i][c] = sum_k A[i][k] B[c][k]) with k contiguous for both operands.
+//
+// Operand tile = 128 rows x 32 k of one plane = [128][32] bf16 = 8 KB; the three planes of a tile are adjacent
+// (24 KB) and tiles are stored tile-major:  tile(rb, kt) at ((rb * ntk + kt) * 3 + plane) * 4096 elements.
+// One wave-wide 16-byte-per-lane load therefore covers 1 KB of consecutive memory (row-major planes made every
+// 64-byte row piece its own cache-line visit: the producers spent 2900 cycles per k tile issuing loads).
+//   T3   rows = particles, k = parameters   (distance operands; rows of a tile may straddle two row blocks when a
+//        rank's row0 is not a multiple of 128, so this image is NOT pre-swizzled)
+//   Vt3  rows = parameters, k = particles   (theta^T and score^T: the contraction's B operand; tiles are always
+//        aligned, so each row's four 16-byte chunks are stored already XOR-swizzled and a tile copies to LDS verbatim)
+//
+// LDS image of a plane: [128 rows][64 B], chunk c of row r at 16 * (c ^ ((r >> 2) & 3)).  Conflict-free for
 //   ds_read_b128 fragments (16-lane groups {0-3,12-15,20-27}..., 64 banks): (4 row + chunk') mod 16 distinct in a group
 //   ds_write_b128 staging  (8 consecutive lanes = 2 rows x 4 chunks, 32 banks): even row -> bytes 0..63, odd -> 64..127
 //   ds_write_b64 of P      (16 consecutive lanes = 2 rows x 8 half-chunks): same split
-// (an 80-byte padded row made every write 2-way conflicted: SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles.)
-#ifdef STEIN_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of wave 0 of every workgroup
+// (an 80-byte padded row made every write 2-way conflicted.)  Lane l of a 32x32x16 MFMA reads the 8 consecutive k
+// of row (l & 31) at k offset 8 (l >> 5).
+
+#include "stein_x3.h"
+
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // staging registers (native vector: stays in VGPRs)
+
+#ifdef STEIN_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of one wave per role and workgroup
 __device__ u64 g_stamps[8];
 #define STAMP(k)                                                                  \
   do {                                                                            \
@@ -51,14 +60,13 @@ extern "C" int stein_debug_stamps(u64* host_out, int reset) {
 
 constexpr int XROW = 64;                 // bytes per LDS row: 32 bf16
 constexpr int XPLANE = 128 * XROW;       // one 128-row plane of a tile: 8192 B
-constexpr int XOPER = 3 * XPLANE;        // three planes of one operand: 24576 B
+constexpr int XOPER = 3 * XPLANE;        // three planes of one operand tile: 24576 B
+constexpr int XTILE_E = 128 * 32;        // elements of one plane of a tile
 __device__ __forceinline__ int xswz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
 
 // ------------------------------------------------------------------------------------------------
 // splitting
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf16_bits_to_f32(u32 b) { return __uint_as_float(b << 16); }
-
 __device__ __forceinline__ u32 cvt_pk_bf16(float lo, float hi) {   // round-to-nearest-even, lo -> bits 15:0
   u32 r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -74,14 +82,17 @@ __device__ __forceinline__ void split3_pair(float x, float y, u32& hi, u32& mid,
   lo = cvt_pk_bf16(sx, sy);
 }
 
-// One 64x64 tile of X per workgroup.  R (row-major planes, [3][r_rows][dk]) and/or Tt (transposed planes,
-// [3][dc][nk]) may be NULL.  The grid covers the padded extents; out-of-range source entries are zero.
+// One 64x64 tile of X [n][d] per workgroup.
+//   R  != NULL: tile-major image with rows = X rows (dk / 32 k tiles per row block), not swizzled, rows < r_rows, k < dk
+//   Tt != NULL: tile-major image with rows = X columns (nk / 32 k tiles per row block), pre-swizzled, rows < dc, k < nk
+// The grid covers the padded extents; out-of-range source entries are written as zero.
 __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int n, int d, u16* __restrict__ R,
                                                 long r_rows, int dk, u16* __restrict__ Tt, int dc, long nk) {
   __shared__ u16 tile[3][64][66];
   const int t = threadIdx.x;
   const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
   const int lr = t >> 4, lc = (t & 15) * 4;
+  const long ntk_r = dk >> 5, ntk_t = nk >> 5;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int row = row0 + lr + 16 * p, col = col0 + lc;
@@ -91,11 +102,11 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int
     u32 h0, m0, l0, h1, m1, l1;
     split3_pair(v[0], v[1], h0, m0, l0);
     split3_pair(v[2], v[3], h1, m1, l1);
-    if (R && row < r_rows && col < dk) {   // dk % 32 == 0 and col % 4 == 0: the 4 entries stay inside the row
-      const size_t o = (size_t)row * dk + col;
-      *reinterpret_cast<uint2*>(R + o) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(R + (size_t)r_rows * dk + o) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(R + 2 * (size_t)r_rows * dk + o) = make_uint2(l0, l1);
+    if (R && row < r_rows && col < dk) {   // col % 4 == 0: the 4 entries stay inside one 32-wide k tile
+      u16* dst = R + (((size_t)(row >> 7) * ntk_r + (col >> 5)) * 3) * XTILE_E + (row & 127) * 32 + (col & 31);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + XTILE_E) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(dst + 2 * XTILE_E) = make_uint2(l0, l1);
     }
     if (Tt) {
       const int rr = lr + 16 * p;
@@ -109,39 +120,41 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int
   }
   if (!Tt) return;
   __syncthreads();
-  // transposed store: thread -> (parameter c = t >> 2, 16 particles starting at 16 (t & 3))
+  // transposed store: thread -> (parameter c = t >> 2, the 16 particles starting at j = row0 + 16 (t & 3)) = 2 chunks
   const int c = col0 + (t >> 2), j = row0 + (t & 3) * 16;
-  if (c < dc && j < nk) {   // nk % 32 == 0 and j % 16 == 0: 16 entries stay inside the row
+  if (c < dc && j < nk) {   // nk % 32 == 0 and j % 16 == 0: both chunks stay inside one k tile
+    const int rowc = c & 127, ch0 = (j & 31) >> 3;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       u32 w[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         w[q] = (u32)tile[s][t >> 2][(t & 3) * 16 + 2 * q] | ((u32)tile[s][t >> 2][(t & 3) * 16 + 2 * q + 1] << 16);
-      u16* dst = Tt + (size_t)s * dc * nk + (size_t)c * nk + j;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+      u16* base = Tt + (((size_t)(c >> 7) * ntk_t + (j >> 5)) * 3 + s) * XTILE_E + rowc * 32;
+      *reinterpret_cast<uint4*>(base + (xswz(rowc, ch0) >> 1)) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(base + (xswz(rowc, ch0 + 1) >> 1)) = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared pieces of the two MFMA kernels
+// k_distance_x3
+//   Thread t stages chunk t and chunk t + 256 (row += 64) of every plane.  The tile's rows may straddle two row
+//   blocks of T3, so each thread keeps its two source pointers; k tile / plane steps are uniform immediates.
 // ------------------------------------------------------------------------------------------------
-// global -> registers: one operand tile = 3 planes x 128 rows x 32 k (64 B per row) = 3 x 512 16-byte chunks;
-// thread t owns chunks t and t + 256 (64 rows further down) of every plane.  Rows and k are padded in memory: no
-// bounds checks.  `tile` is wave-uniform (scalar address arithmetic); `toff` = (t >> 2) * ld + (t & 3) * 8 is the
-// only per-lane part and is loop invariant.
-__device__ __forceinline__ void x3_load_tile(const u16* __restrict__ tile, size_t plane_stride, long ld, u32 toff,
-                                             u32x4 (&reg)[6]) {
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      reg[s * 2 + q] = *reinterpret_cast<const u32x4*>(tile + s * plane_stride + (size_t)q * 64 * ld + toff);
+__device__ __forceinline__ const u16* t3_chunk_ptr(const u16* __restrict__ T3, long ntk, long grow, int c16) {
+  return T3 + ((size_t)(grow >> 7) * ntk * 3) * XTILE_E + (grow & 127) * 32 + c16 * 8;
 }
 
-__device__ __forceinline__ void x3_store_tile(unsigned char* oper, int t, const u32x4 (&reg)[6]) {
+__device__ __forceinline__ void t3_load(const u16* __restrict__ p0, const u16* __restrict__ p1, int kt, u32x4 (&reg)[6]) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    reg[s * 2 + 0] = *reinterpret_cast<const u32x4*>(p0 + ((size_t)kt * 3 + s) * XTILE_E);
+    reg[s * 2 + 1] = *reinterpret_cast<const u32x4*>(p1 + ((size_t)kt * 3 + s) * XTILE_E);
+  }
+}
+
+__device__ __forceinline__ void x3_store_swz(unsigned char* oper, int t, const u32x4 (&reg)[6]) {
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -183,11 +196,8 @@ __device__ __forceinline__ void x3_mma_tile(const unsigned char* As, const unsig
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_distance_x3
-// ------------------------------------------------------------------------------------------------
 template <bool SYM>
-__global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restrict__ T3, size_t plane_stride, int dk,
+__global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restrict__ T3, int ntk,
                                                              const float* __restrict__ r, float* __restrict__ D, int n,
                                                              int row0, int n_local, long ldD, int tiles_m, int tiles_n,
                                                              u64* __restrict__ hist0) {
@@ -208,19 +218,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  const u16* __restrict__ pa0 = t3_chunk_ptr(T3, ntk, arow0 + (t >> 2), t & 3);
+  const u16* __restrict__ pa1 = t3_chunk_ptr(T3, ntk, arow0 + (t >> 2) + 64, t & 3);
+  const u16* __restrict__ pb0 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2), t & 3);
+  const u16* __restrict__ pb1 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2) + 64, t & 3);
   u32x4 ra[6], rb[6];
-  const u32 toff = (u32)(t >> 2) * (u32)dk + (u32)(t & 3) * 8u;
-  const u16* __restrict__ pa = T3 + (size_t)arow0 * dk;   // wave-uniform tile origins
-  const u16* __restrict__ pb = T3 + (size_t)brow0 * dk;
-  x3_load_tile(pa, plane_stride, dk, toff, ra);
-  x3_load_tile(pb, plane_stride, dk, toff, rb);
-  for (int k0 = 0; k0 < dk; k0 += BK) {
-    x3_store_tile(As, t, ra);
-    x3_store_tile(Bs, t, rb);
+  t3_load(pa0, pa1, 0, ra);
+  t3_load(pb0, pb1, 0, rb);
+  for (int kt = 0; kt < ntk; ++kt) {
+    x3_store_swz(As, t, ra);
+    x3_store_swz(Bs, t, rb);
     __syncthreads();
-    if (k0 + BK < dk) {
-      x3_load_tile(pa + k0 + BK, plane_stride, dk, toff, ra);
-      x3_load_tile(pb + k0 + BK, plane_stride, dk, toff, rb);
+    if (kt + 1 < ntk) {
+      t3_load(pa0, pa1, kt + 1, ra);
+      t3_load(pb0, pb1, kt + 1, rb);
     }
     x3_mma_tile(As, Bs, wy, wx, lane, acc);
     __syncthreads();
@@ -229,115 +240,239 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_phi_x3
+// k_phi_x3ws: the contraction, warp-specialised.
+//   A monolithic version (every wave stages, then every wave multiplies) stalled three ways (phase stamps,
+//   STEIN_STAMPS build): its two workgroups per CU fell into lockstep (exp/split phase together, MFMA phase
+//   together), every wave blocked while its operand loads were accepted at the vector-L1 rate, and the 128-wide
+//   tile needed 40 KB of L2 traffic per 1536 MFMA cycles.  Here one 512-thread workgroup owns a 128 x 256 tile:
+//     waves 0-3  PRODUCERS  load the D tile and the V tiles, P = exp2(c D), split, fill LDS stage (it+1) & 1
+//     waves 4-7  CONSUMERS  ds_read fragments from LDS stage it & 1 and issue nothing but MFMAs (96 per k tile)
+//   Wave w and w + 4 share a SIMD, so every SIMD runs one VALU/memory wave beside one matrix wave; load
+//   back-pressure and exp latency only ever stall a producer.  One barrier per k tile hands the stages over.
+//   Column space: the 128-column blocks of [G | theta] (each matrix padded to dc = roundup(d, 128)) are paired up,
+//   block cb covers pair (2cb, 2cb+1); each half picks its own source tiles and output matrix.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS, 2) void k_phi_x3(const float* __restrict__ D, long ldD,
-                                                        const u16* __restrict__ Gt3, const u16* __restrict__ Tt3,
-                                                        size_t plane_stride, long nk, const float* __restrict__ h2p,
-                                                        float* __restrict__ OG, float* __restrict__ OT,
-                                                        float* __restrict__ RS, int n, int d, int n_local, int tiles_m,
-                                                        int cblocks, int split, int jchunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XOPER];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + XOPER;
+constexpr int WS_THREADS = 512;
+constexpr int WS_A = XOPER;            // P planes, 128 rows:            24576 B
+constexpr int WS_B = 2 * XOPER;        // V planes, two 128-row halves:  49152 B
+constexpr int WS_BUF = WS_A + WS_B;    // one pipeline stage:            73728 B  (two stages: 147456 B of the 160 KiB)
+
+// a pre-swizzled V tile (3 planes, 24 KB contiguous): thread pt copies chunks pt and pt + 256 of each plane
+__device__ __forceinline__ void vt3_load(const u16* __restrict__ tile, int pt, u32x4 (&reg)[6]) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      reg[s * 2 + q] = *reinterpret_cast<const u32x4*>(tile + s * XTILE_E + q * 2048 + pt * 8);
+}
+__device__ __forceinline__ void vt3_store(unsigned char* oper, int pt, const u32x4 (&reg)[6]) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      *reinterpret_cast<u32x4*>(oper + s * XPLANE + q * 4096 + pt * 16) = reg[s * 2 + q];
+}
+
+__global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restrict__ D, long ldD,
+                                                            const u16* __restrict__ Gt3, const u16* __restrict__ Tt3,
+                                                            long ntj, const float* __restrict__ h2p,
+                                                            float* __restrict__ OG, float* __restrict__ OT,
+                                                            float* __restrict__ RS, int n, int d, int n_local,
+                                                            int tiles_m, int cblocks, int split, int jchunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WS_BUF];
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int ncb = 2 * cblocks;
-  const int cb = logical % ncb;
-  const int tile_m = (logical / ncb) % tiles_m;
-  const int z = logical / (ncb * tiles_m);
-  const bool isT = cb >= cblocks;
-  const u16* __restrict__ V3 = isT ? Tt3 : Gt3;
-  float* __restrict__ O = isT ? OT : OG;
-  const int c0 = (isT ? cb - cblocks : cb) * BN;
+  const int cb = logical % cblocks;
+  const int tile_m = (logical / cblocks) % tiles_m;
+  const int z = logical / (cblocks * tiles_m);
+  const int i0 = tile_m * BM;
   const int jbeg = z * jchunk;
   const int jend = min(n, jbeg + jchunk);
+  const int ntile = jend > jbeg ? (jend - jbeg + BK - 1) / BK : 0;
 
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wy = wid >> 1, wx = wid & 1;
-  const int lr = t >> 3, lc = (t & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
-  const int i0 = tile_m * BM;
-  const float cexp = -1.44269504088896341f / (2.f * *h2p);  // exp(-D/(2 h2)) = exp2(cexp * D)
-
-  f32x16 acc[2][2];
+  const int t = threadIdx.x;
+  // The two roles run separate loops (so neither carries the other's registers) with the same number of
+  // barriers: one after the prologue, one per k tile.  The role test is wave-uniform (waves 0-3 / 4-7).
+  if (t < 256) {
+    // ================================ PRODUCER ================================
+    const int pt = t;
+    const int lr = pt >> 3, lc = (pt & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    // two register sets (X for even tiles, Y for odd): the loads of tile t+2 are issued as soon as tile t has been
+    // turned into LDS data, so they fly during the whole production of tile t+1 and the barrier wait behind it
+    float4 rdX[4], rdY[4];
+    u32x4 rvX0[6], rvX1[6], rvY0[6], rvY1[6];
+    u32 doff[4];
+    const u16* __restrict__ pv[2];   // wave-uniform: first tile (k tile 0) of each half's 128-column block
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int hh = 0; hh < 2; ++hh) {
+      const int g = 2 * cb + hh;   // 128-column block of [G | theta]
+      pv[hh] = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E);
+    }
+    const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
+    // D rows are clamped to the block (rows past n_local only feed accumulator rows that are never stored)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int p = 0; p < 4; ++p) doff[p] = (u32)min(i0 + lr + 32 * p, n_local - 1) * (u32)ldD + (u32)lc;
+    auto issue_loads = [&](int j0, float4 (&rd)[4], u32x4 (&rv0)[6], u32x4 (&rv1)[6]) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float rs[4] = {0.f, 0.f, 0.f, 0.f};
-
-  float4 rd[4];
-  u32x4 rv[6];
-  const u32 voff = (u32)(t >> 2) * (u32)nk + (u32)(t & 3) * 8u;
-  const u16* __restrict__ pv0 = V3 + (size_t)c0 * nk;   // wave-uniform origin of this column block's rows
-  // D rows are clamped to the block (rows past n_local only feed accumulator rows that are never stored), so the
-  // loads need no predicate; ldD >= roundup(n, 64) keeps j0 + 31 inside the row.
-  u32 doff[4];
+      for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(D + j0 + doff[p]);
+      const size_t toff = (size_t)(j0 >> 5) * 3 * XTILE_E;
+      vt3_load(pv[0] + toff, pt, rv0);
+      vt3_load(pv[1] + toff, pt, rv1);
+    };
+    // registers of tile j0 -> LDS stage `buf`
+    auto produce = [&](int j0, unsigned char* buf, const float4 (&rd)[4], const u32x4 (&rv0)[6], const u32x4 (&rv1)[6]) {
+      const bool full = j0 + BK <= jend;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) doff[p] = (u32)min(i0 + lr + 32 * p, n_local - 1) * (u32)ldD + (u32)lc;
-  auto load_d = [&](int j0) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(D + j0 + doff[p]);
-  };
-  if (jbeg < jend) {
-    load_d(jbeg);
-    x3_load_tile(pv0 + jbeg, plane_stride, nk, voff, rv);
-  }
-#ifdef STEIN_STAMPS
-  u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
-  u64 st_last = __builtin_amdgcn_s_memtime();
-#endif
-  for (int j0 = jbeg; j0 < jend; j0 += BK) {
-    const bool full = j0 + BK <= jend;   // wave-uniform: only the last tile of the last split can be ragged
-#ifdef STEIN_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    STAMP(0);   // waiting for the prefetched tile
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float4 pv;
-      pv.x = __builtin_amdgcn_exp2f(cexp * rd[p].x);
-      pv.y = __builtin_amdgcn_exp2f(cexp * rd[p].y);
-      pv.z = __builtin_amdgcn_exp2f(cexp * rd[p].z);
-      pv.w = __builtin_amdgcn_exp2f(cexp * rd[p].w);
-      if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
-        const int j = j0 + lc;
-        pv.x = (j + 0 < jend) ? pv.x : 0.f;
-        pv.y = (j + 1 < jend) ? pv.y : 0.f;
-        pv.z = (j + 2 < jend) ? pv.z : 0.f;
-        pv.w = (j + 3 < jend) ? pv.w : 0.f;
+      for (int p = 0; p < 4; ++p) {
+        float4 q4;
+        q4.x = __builtin_amdgcn_exp2f(cexp * rd[p].x);
+        q4.y = __builtin_amdgcn_exp2f(cexp * rd[p].y);
+        q4.z = __builtin_amdgcn_exp2f(cexp * rd[p].z);
+        q4.w = __builtin_amdgcn_exp2f(cexp * rd[p].w);
+        if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
+          const int j = j0 + lc;
+          q4.x = (j + 0 < jend) ? q4.x : 0.f;
+          q4.y = (j + 1 < jend) ? q4.y : 0.f;
+          q4.z = (j + 2 < jend) ? q4.z : 0.f;
+          q4.w = (j + 3 < jend) ? q4.w : 0.f;
+        }
+        rs[p] += (q4.x + q4.y) + (q4.z + q4.w);
+        u32 h0, m0, l0, h1, m1, l1;
+        split3_pair(q4.x, q4.y, h0, m0, l0);
+        split3_pair(q4.z, q4.w, h1, m1, l1);
+        unsigned char* dst = buf + (lr + 32 * p) * XROW + xswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = make_uint2(l0, l1);
       }
-      rs[p] += (pv.x + pv.y) + (pv.z + pv.w);
-      u32 h0, m0, l0, h1, m1, l1;
-      split3_pair(pv.x, pv.y, h0, m0, l0);
-      split3_pair(pv.z, pv.w, h1, m1, l1);
-      unsigned char* dst = As + (lr + 32 * p) * XROW + xswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr + 32p) >> 2 & 3 == lr >> 2 & 3
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = make_uint2(l0, l1);
-    }
-    x3_store_tile(Bs, t, rv);
-    STAMP(1);   // exp + split + LDS writes
-    __syncthreads();
-    STAMP(2);   // barrier 1
-    if (j0 + BK < jend) {
-      load_d(j0 + BK);
-      x3_load_tile(pv0 + j0 + BK, plane_stride, nk, voff, rv);
-    }
-    STAMP(3);   // prefetch issue
-    x3_mma_tile(As, Bs, wy, wx, lane, acc);
-    STAMP(4);   // LDS fragment reads + MFMAs
-    __syncthreads();
-    STAMP(5);   // barrier 2
-  }
+      vt3_store(buf + WS_A, pt, rv0);
+      vt3_store(buf + WS_A + XOPER, pt, rv1);
+    };
+    auto jt = [&](int tile) { return jbeg + tile * BK; };   // tile index -> first column (jbeg % 32 == 0)
 #ifdef STEIN_STAMPS
-  if (t == 0)
-    for (int k = 0; k < 6; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
-  if (t == 0) atomicAdd(&g_stamps[7], 1ull);
+    u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
+    u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
-  phi_epilogue(acc, rs, O + (size_t)z * n_local * d, RS + (size_t)z * n_local, d, n_local, i0, c0, cb == 0);
+    if (ntile > 0) issue_loads(jt(0), rdX, rvX0, rvX1);
+    if (ntile > 1) issue_loads(jt(1), rdY, rvY0, rvY1);
+    if (ntile > 0) {
+      produce(jt(0), smem, rdX, rvX0, rvX1);
+      if (ntile > 2) issue_loads(jt(2), rdX, rvX0, rvX1);
+    }
+    __syncthreads();
+    // iteration `it` (consumers are on tile it): turn tile it+1 into LDS stage (it+1)&1, then fetch tile it+3
+    for (int it = 0; it < ntile; it += 2) {
+      if (it + 1 < ntile) {
+        STAMP(5);
+        produce(jt(it + 1), smem + WS_BUF, rdY, rvY0, rvY1);
+        STAMP(0);   // produce (includes waiting for the tile's loads)
+        if (it + 3 < ntile) issue_loads(jt(it + 3), rdY, rvY0, rvY1);
+        STAMP(1);   // issue
+      }
+      __syncthreads();
+      STAMP(2);     // barrier
+      if (it + 1 < ntile) {   // second half of the unrolled pair: consumers are on tile it+1
+        if (it + 2 < ntile) {
+          produce(jt(it + 2), smem, rdX, rvX0, rvX1);
+          STAMP(0);
+          if (it + 4 < ntile) issue_loads(jt(it + 4), rdX, rvX0, rvX1);
+          STAMP(1);
+        }
+        __syncthreads();
+        STAMP(2);
+      }
+    }
+#ifdef STEIN_STAMPS
+    if (t == 0) {
+      for (int k = 0; k < 3; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+      atomicAdd(&g_stamps[7], 1ull);
+    }
+#endif
+    if (cb == 0) {   // rowsum: the 8 threads of a row are 8 consecutive lanes
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float sum = rs[p];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        const int row = i0 + lr + 32 * p;
+        if ((pt & 7) == 0 && row < n_local) RS[(size_t)z * n_local + row] = sum;
+      }
+    }
+  } else {
+    // ================================ CONSUMER ================================
+    const int ct = t - 256, lane = ct & 63, cw = ct >> 6;
+    const int wy = cw >> 1, wx = cw & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    __syncthreads();
+#ifdef STEIN_STAMPS
+    u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
+    u64 st_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (int it = 0; it < ntile; ++it) {
+      STAMP(5);
+      const unsigned char* As = smem + (it & 1) * WS_BUF;
+      const unsigned char* Bs = As + WS_A + wx * XOPER;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[2][3], b[4][3];
+        const int co = xswz(l31, 2 * ks + h);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            a[i][s] = *reinterpret_cast<const bf16x8*>(As + s * XPLANE + (wy * 64 + i * 32 + l31) * XROW + co);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            b[j][s] = *reinterpret_cast<const bf16x8*>(Bs + s * XPLANE + (j * 32 + l31) * XROW + co);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x16 c = acc[i][j];
+            // smallest terms first (planes: 0 = hi, 1 = mid, 2 = lo)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+      STAMP(3);   // consumer: fragment reads + MFMAs
+      __syncthreads();
+      STAMP(4);   // consumer: barrier
+    }
+#ifdef STEIN_STAMPS
+    if (t == 256)
+      for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+#endif
+    const int g = 2 * cb + wx;   // this wave's 128-column block
+    float* __restrict__ Oz = (g < cblocks ? OG : OT) + (size_t)z * n_local * d;
+    const int cbase = (g < cblocks ? g : g - cblocks) * BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = cbase + j * 32 + l31;
+        if (col >= d) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = i0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e];
+        }
+      }
+  }
 }
 
 // ================================================================================================
@@ -355,7 +490,7 @@ int stein_x3_split(const float* theta_all, const float* score_all, int64_t n, in
                      (int)L.x3_dk, Tt3, (int)L.x3_dc, (long)L.x3_nk);
   LAUNCH_CHECK("k_split3(theta)");
   const dim3 grid_g((unsigned)((L.x3_dc + 63) / 64), (unsigned)((L.x3_nk + 63) / 64));
-  hipLaunchKernelGGL(k_split3, grid_g, dim3(256), 0, stream, score_all, (int)n, (int)d, (u16*)nullptr, 0l, 0, Gt3,
+  hipLaunchKernelGGL(k_split3, grid_g, dim3(256), 0, stream, score_all, (int)n, (int)d, (u16*)nullptr, 0l, 32, Gt3,
                      (int)L.x3_dc, (long)L.x3_nk);
   LAUNCH_CHECK("k_split3(score)");
   return STEIN_OK;
@@ -366,18 +501,16 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, const float* r_a
                       hipStream_t stream) {
   (void)d;
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
-  const size_t plane_stride = (size_t)L.x3_rows * L.x3_dk;
+  const int ntk = (int)(L.x3_dk / 32);
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
   if (row0 + (int64_t)tiles_m * BM > L.x3_rows) return stein_fail(STEIN_E_SHAPE, "row block exceeds the padded planes");
   const long nblk = symmetric ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
   if (symmetric)
-    hipLaunchKernelGGL((k_distance_x3<true>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, plane_stride,
-                       (int)L.x3_dk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n,
-                       hist0);
+    hipLaunchKernelGGL((k_distance_x3<true>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r_all, dist_out,
+                       (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
   else
-    hipLaunchKernelGGL((k_distance_x3<false>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, plane_stride,
-                       (int)L.x3_dk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n,
-                       hist0);
+    hipLaunchKernelGGL((k_distance_x3<false>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r_all, dist_out,
+                       (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
   LAUNCH_CHECK("k_distance_x3");
   return STEIN_OK;
 }
@@ -387,11 +520,10 @@ int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* pl
                               int64_t n_local, hipStream_t stream) {
   const u16* Tt3 = reinterpret_cast<const u16*>(planes + L.x3_tt3);
   const u16* Gt3 = reinterpret_cast<const u16*>(planes + L.x3_gt3);
-  const size_t plane_stride = (size_t)L.x3_dc * L.x3_nk;
-  const long nblk = (long)L.tiles_m * 2 * L.cblocks * L.split;
-  hipLaunchKernelGGL(k_phi_x3, dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
-                     plane_stride, (long)L.x3_nk, h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
+  const long nblk = (long)L.tiles_m * L.cblocks * L.split;
+  hipLaunchKernelGGL(k_phi_x3ws, dim3((unsigned)nblk), dim3(WS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
+                     (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
                      (int)L.cblocks, (int)L.split, (int)L.jchunk);
-  LAUNCH_CHECK("k_phi_x3");
+  LAUNCH_CHECK("k_phi_x3ws");
   return STEIN_OK;
 }

@@ -530,12 +530,15 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
-  const int64_t base = L->tiles_m * 2 * L->cblocks;
+  // workgroups per unit of split and resident workgroups per round: the fp32 kernel tiles [G | theta] in 128-column
+  // blocks at 3 workgroups per CU; the split-bf16 kernel pairs the blocks up (256 columns) at 1 workgroup per CU
+  const bool x3 = (flags & STEIN_FLAG_X3) != 0;
+  const int64_t base = x3 ? L->tiles_m * L->cblocks : L->tiles_m * 2 * L->cblocks;
   const int64_t jt = (n + BK - 1) / BK;  // j tiles
   // k_phi_partial runs 3 workgroups per CU (156 registers): 768 resident blocks.  Every block does the same
   // work, so the launch takes ceil(blocks / 768) rounds; pick the j-split that wastes least of the last round
   // (ties -> fewer splits, i.e. less partial traffic), keeping at least 8 j-tiles (256 columns) per split.
-  const double resident = (flags & STEIN_FLAG_X3) ? 512.0 : 768.0;  // the split-bf16 kernel fits 2 workgroups per CU
+  const double resident = x3 ? 256.0 : 768.0;
   int64_t max_split = jt / 8 > 0 ? jt / 8 : 1;
   if (max_split > 16) max_split = 16;
   int64_t split = 1;

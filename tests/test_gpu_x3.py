@@ -31,11 +31,21 @@ def test_split_planes_reconstruct_fp32(cuda):
     rows, dk = (n + 127) // 128 * 128 + 128, (d + 31) // 32 * 32
     dc, nk = (d + 127) // 128 * 128, (n + 31) // 32 * 32
     raw = eng.planes.view(torch.bfloat16)
-    t3 = raw[:3 * rows * dk].view(3, rows, dk).float().sum(0)
+
+    def untile(flat, nrows, nks, swizzled):
+        """tile-major image [row blocks][k tiles][3 planes][128][32] -> summed fp32 matrix [nrows, nks]"""
+        x = flat.view(nrows // 128, nks // 32, 3, 128, 4, 8).float()
+        if swizzled:      # chunk c of row r is stored at c ^ ((r >> 2) & 3)
+            r = torch.arange(128, device=flat.device)
+            src = (torch.arange(4, device=flat.device)[None, :] ^ ((r >> 2) & 3)[:, None])       # [128, 4]
+            x = torch.gather(x, 4, src[None, None, None, :, :, None].expand_as(x))
+        return x.sum(2).permute(0, 2, 1, 3, 4).reshape(nrows, nks)
+
+    t3 = untile(raw[:3 * rows * dk], rows, dk, False)
     off = (3 * rows * dk * 2 + 255) // 256 * 256 // 2
-    tt3 = raw[off:off + 3 * dc * nk].view(3, dc, nk).float().sum(0)
+    tt3 = untile(raw[off:off + 3 * dc * nk], dc, nk, True)
     off2 = off + (3 * dc * nk * 2 + 255) // 256 * 256 // 2
-    gt3 = raw[off2:off2 + 3 * dc * nk].view(3, dc, nk).float().sum(0)
+    gt3 = untile(raw[off2:off2 + 3 * dc * nk], dc, nk, True)
     tol = 2.0 ** -23
     assert ((t3[:n, :d] - T).abs() <= tol * T.abs()).all()
     assert (t3[n:].abs().max() == 0) and (t3[:, d:].abs().max() == 0)          # zero padding
