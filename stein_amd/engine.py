@@ -95,9 +95,11 @@ class SvgdEngine:
 
     def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None):
         self.n, self.d = int(n), int(d)
-        # x3: run both GEMMs as split-bf16 (three bf16 terms per fp32 operand) on the bf16 matrix cores
+        # x3 (default): both GEMMs run on the bf16 matrix cores with every fp32 operand split into three bf16
+        # terms -- fp32-level accuracy at a fraction of the fp32-MFMA time.  x3=False (or STEIN_X3=0) selects the
+        # fp32-input MFMA kernels (an exact k-ordered fmaf chain).
         if x3 is None:
-            x3 = os.environ.get("STEIN_X3", "0") not in ("0", "", "false")
+            x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
         self.x3 = bool(x3)
         self.flags = _lib.FLAG_X3 if self.x3 else 0
         self.device = torch.device(device)

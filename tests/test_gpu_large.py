@@ -97,7 +97,7 @@ def test_c3_row_block_equals_full(cuda):
     gen = torch.Generator(device="cpu").manual_seed(5)
     T = torch.randn(n, d, generator=gen).to(cuda)
     G = torch.randn(n, d, generator=gen).to(cuda)
-    full = SvgdEngine(n, d, device=cuda)
+    full = SvgdEngine(n, d, device=cuda, x3=False)   # bitwise block == full only holds for the fp32-MFMA kernels
     phi_full = full.compute_phi(T, G).clone()
 
     nl = n // parts
