@@ -120,8 +120,11 @@ int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, i
  * offsets[STEIN_WS_PLANES], planes_bytes = total - offsets[STEIN_WS_PLANES]) with the three bf16 terms of every
  * entry of theta (row-major and transposed) and of the score (transposed).  Passing the same pointer as
  * `x3_planes` to stein_distance_block / stein_contract_partial / stein_kernel_contract selects the bf16-MFMA
- * kernels there; NULL selects the fp32-MFMA kernels. */
-int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, void* x3_planes,
+ * kernels there; NULL selects the fp32-MFMA kernels.
+ * dtype = STEIN_BF16 (BASELINE config 2): theta_all / score_all hold bf16 values; they are the single operand plane,
+ * K is rounded to bf16 once (its rowsum uses the rounded values), every product is one bf16 MFMA with fp32
+ * accumulation.  bf16 inputs always need STEIN_FLAG_X3 / the planes. */
+int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, int dtype, void* x3_planes,
                      size_t planes_bytes, void* stream);
 
 /* Exact median of all n*n distances by 3-level radix select on the fp32 bit pattern.

@@ -31,7 +31,7 @@ _SIGNATURES = {
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_rownorms": [_vp, _i64, _i64, _int, _vp, _vp],
     "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _int, _vp],
-    "stein_x3_prepare": [_vp, _vp, _i64, _i64, _vp, _sz, _vp],
+    "stein_x3_prepare": [_vp, _vp, _i64, _i64, _int, _vp, _sz, _vp],
     "stein_median_begin": [_vp, _vp, _i64, _vp],
     "stein_median_hist_pass": [_vp, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp],
     "stein_median_resolve": [_vp, _int, _i64, _vp, _vp, _vp, _vp],

@@ -2,11 +2,12 @@
 #pragma once
 #include "stein_common.h"
 
-int stein_x3_split(const float* theta_all, const float* score_all, int64_t n, int64_t d, const SteinLayout& L,
+// dtype = STEIN_F32: fp32 inputs, three bf16 planes, six products; STEIN_BF16: bf16 inputs, one plane, one product
+int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d, const SteinLayout& L,
                    char* planes, hipStream_t stream);
-int stein_x3_distance(const char* planes, const SteinLayout& L, const float* r_all, float* dist_out, int64_t n,
-                      int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
+int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
+                      int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
                       hipStream_t stream);
-int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L,
+int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L, int dtype,
                               const float* h2_dev, float* OG, float* OT, float* RS, int64_t n, int64_t d,
                               int64_t n_local, hipStream_t stream);

@@ -86,7 +86,13 @@ __device__ __forceinline__ void split3_pair(float x, float y, u32& hi, u32& mid,
 //   R  != NULL: tile-major image with rows = X rows (dk / 32 k tiles per row block), not swizzled, rows < r_rows, k < dk
 //   Tt != NULL: tile-major image with rows = X columns (nk / 32 k tiles per row block), pre-swizzled, rows < dc, k < nk
 // The grid covers the padded extents; out-of-range source entries are written as zero.
-__global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int n, int d, u16* __restrict__ R,
+__device__ __forceinline__ float load_as_f32(const float* p) { return *p; }
+__device__ __forceinline__ float load_as_f32(const u16* p) { return __uint_as_float((u32)*p << 16); }   // bf16 bits
+
+// TIN = float (three planes: hi, mid, lo) or u16 = bf16 bits (the value IS the hi plane; mid = lo = 0 are written too,
+// so a bf16 image can be consumed by either kernel variant).
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_split3(const TIN* __restrict__ X, int n, int d, u16* __restrict__ R,
                                                 long r_rows, int dk, u16* __restrict__ Tt, int dc, long nk) {
   __shared__ u16 tile[3][64][66];
   const int t = threadIdx.x;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int
     const int row = row0 + lr + 16 * p, col = col0 + lc;
     float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (row < n && col + q < d) ? X[(size_t)row * d + col + q] : 0.f;
+    for (int q = 0; q < 4; ++q) v[q] = (row < n && col + q < d) ? load_as_f32(X + (size_t)row * d + col + q) : 0.f;
     u32 h0, m0, l0, h1, m1, l1;
     split3_pair(v[0], v[1], h0, m0, l0);
     split3_pair(v[2], v[3], h1, m1, l1);
@@ -146,17 +152,19 @@ __device__ __forceinline__ const u16* t3_chunk_ptr(const u16* __restrict__ T3, l
   return T3 + ((size_t)(grow >> 7) * ntk * 3) * XTILE_E + (grow & 127) * 32 + c16 * 8;
 }
 
+template <int NP>
 __device__ __forceinline__ void t3_load(const u16* __restrict__ p0, const u16* __restrict__ p1, int kt, u32x4 (&reg)[6]) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < NP; ++s) {
     reg[s * 2 + 0] = *reinterpret_cast<const u32x4*>(p0 + ((size_t)kt * 3 + s) * XTILE_E);
     reg[s * 2 + 1] = *reinterpret_cast<const u32x4*>(p1 + ((size_t)kt * 3 + s) * XTILE_E);
   }
 }
 
+template <int NP>
 __device__ __forceinline__ void x3_store_swz(unsigned char* oper, int t, const u32x4 (&reg)[6]) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < NP; ++s)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int chunk = t + 256 * q;
@@ -164,7 +172,22 @@ __device__ __forceinline__ void x3_store_swz(unsigned char* oper, int t, const u
     }
 }
 
-// one 32-deep k tile already in LDS: 2 k16 steps x (2x2 tiles) x 6 products
+// the products of one fragment pair: six for the three-term split (smallest first; planes 0 = hi, 1 = mid, 2 = lo),
+// one for plain bf16 operands
+template <int NP>
+__device__ __forceinline__ f32x16 x3_products(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  if (NP == 3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+}
+
+// one 32-deep k tile already in LDS: 2 k16 steps x (2x2 tiles) x NP-dependent products
+template <int NP>
 __device__ __forceinline__ void x3_mma_tile(const unsigned char* As, const unsigned char* Bs, int wy, int wx, int lane,
                                             f32x16 (&acc)[2][2]) {
   const int l31 = lane & 31, h = lane >> 5;
@@ -175,28 +198,18 @@ __device__ __forceinline__ void x3_mma_tile(const unsigned char* As, const unsig
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
+      for (int s = 0; s < NP; ++s) {
         a[i][s] = *reinterpret_cast<const bf16x8*>(As + s * XPLANE + (wy * 64 + i * 32 + l31) * XROW + co);
         b[i][s] = *reinterpret_cast<const bf16x8*>(Bs + s * XPLANE + (wx * 64 + i * 32 + l31) * XROW + co);
       }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];
-        // smallest terms first (planes: 0 = hi, 1 = mid, 2 = lo)
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+      for (int j = 0; j < 2; ++j) acc[i][j] = x3_products<NP>(a[i], b[j], acc[i][j]);
   }
 }
 
-template <bool SYM>
+template <bool SYM, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restrict__ T3, int ntk,
                                                              const float* __restrict__ r, float* __restrict__ D, int n,
                                                              int row0, int n_local, long ldD, int tiles_m, int tiles_n,
@@ -223,17 +236,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
   const u16* __restrict__ pb0 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2), t & 3);
   const u16* __restrict__ pb1 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2) + 64, t & 3);
   u32x4 ra[6], rb[6];
-  t3_load(pa0, pa1, 0, ra);
-  t3_load(pb0, pb1, 0, rb);
+  t3_load<NP>(pa0, pa1, 0, ra);
+  t3_load<NP>(pb0, pb1, 0, rb);
   for (int kt = 0; kt < ntk; ++kt) {
-    x3_store_swz(As, t, ra);
-    x3_store_swz(Bs, t, rb);
+    x3_store_swz<NP>(As, t, ra);
+    x3_store_swz<NP>(Bs, t, rb);
     __syncthreads();
     if (kt + 1 < ntk) {
-      t3_load(pa0, pa1, kt + 1, ra);
-      t3_load(pb0, pb1, kt + 1, rb);
+      t3_load<NP>(pa0, pa1, kt + 1, ra);
+      t3_load<NP>(pb0, pb1, kt + 1, rb);
     }
-    x3_mma_tile(As, Bs, wy, wx, lane, acc);
+    x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
     __syncthreads();
   }
   distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0);
@@ -258,21 +271,24 @@ constexpr int WS_B = 2 * XOPER;        // V planes, two 128-row halves:  49152 B
 constexpr int WS_BUF = WS_A + WS_B;    // one pipeline stage:            73728 B  (two stages: 147456 B of the 160 KiB)
 
 // a pre-swizzled V tile (3 planes, 24 KB contiguous): thread pt copies chunks pt and pt + 256 of each plane
+template <int NP>
 __device__ __forceinline__ void vt3_load(const u16* __restrict__ tile, int pt, u32x4 (&reg)[6]) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < NP; ++s)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       reg[s * 2 + q] = *reinterpret_cast<const u32x4*>(tile + s * XTILE_E + q * 2048 + pt * 8);
 }
+template <int NP>
 __device__ __forceinline__ void vt3_store(unsigned char* oper, int pt, const u32x4 (&reg)[6]) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < NP; ++s)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       *reinterpret_cast<u32x4*>(oper + s * XPLANE + q * 4096 + pt * 16) = reg[s * 2 + q];
 }
 
+template <int NP>
 __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restrict__ D, long ldD,
                                                             const u16* __restrict__ Gt3, const u16* __restrict__ Tt3,
                                                             long ntj, const float* __restrict__ h2p,
@@ -317,8 +333,8 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
 #pragma unroll
       for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(D + j0 + doff[p]);
       const size_t toff = (size_t)(j0 >> 5) * 3 * XTILE_E;
-      vt3_load(pv[0] + toff, pt, rv0);
-      vt3_load(pv[1] + toff, pt, rv1);
+      vt3_load<NP>(pv[0] + toff, pt, rv0);
+      vt3_load<NP>(pv[1] + toff, pt, rv1);
     };
     // registers of tile j0 -> LDS stage `buf`
     auto produce = [&](int j0, unsigned char* buf, const float4 (&rd)[4], const u32x4 (&rv0)[6], const u32x4 (&rv1)[6]) {
@@ -337,17 +353,26 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
           q4.z = (j + 2 < jend) ? q4.z : 0.f;
           q4.w = (j + 3 < jend) ? q4.w : 0.f;
         }
-        rs[p] += (q4.x + q4.y) + (q4.z + q4.w);
-        u32 h0, m0, l0, h1, m1, l1;
-        split3_pair(q4.x, q4.y, h0, m0, l0);
-        split3_pair(q4.z, q4.w, h1, m1, l1);
         unsigned char* dst = buf + (lr + 32 * p) * XROW + xswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
-        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = make_uint2(l0, l1);
+        if (NP == 3) {
+          rs[p] += (q4.x + q4.y) + (q4.z + q4.w);
+          u32 h0, m0, l0, h1, m1, l1;
+          split3_pair(q4.x, q4.y, h0, m0, l0);
+          split3_pair(q4.z, q4.w, h1, m1, l1);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = make_uint2(l0, l1);
+        } else {
+          // bf16 operands: K is rounded to bf16 once and BOTH uses of it (K.theta in the MFMA and rowsum(K) here) see
+          // the rounded value, so the repulsion term sum_j K_ij (theta_i - theta_j) stays consistent
+          const u32 h0 = cvt_pk_bf16(q4.x, q4.y), h1 = cvt_pk_bf16(q4.z, q4.w);
+          rs[p] += (__uint_as_float(h0 << 16) + __uint_as_float(h0 & 0xffff0000u)) +
+                   (__uint_as_float(h1 << 16) + __uint_as_float(h1 & 0xffff0000u));
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        }
       }
-      vt3_store(buf + WS_A, pt, rv0);
-      vt3_store(buf + WS_A + XOPER, pt, rv1);
+      vt3_store<NP>(buf + WS_A, pt, rv0);
+      vt3_store<NP>(buf + WS_A + XOPER, pt, rv1);
     };
     auto jt = [&](int tile) { return jbeg + tile * BK; };   // tile index -> first column (jbeg % 32 == 0)
 #ifdef STEIN_STAMPS
@@ -426,7 +451,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
         bf16x8 a[2][3], b[4][3];
         const int co = xswz(l31, 2 * ks + h);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < NP; ++s) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             a[i][s] = *reinterpret_cast<const bf16x8*>(As + s * XPLANE + (wy * 64 + i * 32 + l31) * XROW + co);
@@ -437,17 +462,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f32x16 c = acc[i][j];
-            // smallest terms first (planes: 0 = hi, 1 = mid, 2 = lo)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-            acc[i][j] = c;
-          }
+          for (int j = 0; j < 4; ++j) acc[i][j] = x3_products<NP>(a[i], b[j], acc[i][j]);
       }
       STAMP(3);   // consumer: fragment reads + MFMAs
       __syncthreads();
@@ -478,26 +493,41 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
 // ================================================================================================
 // host side
 // ================================================================================================
-int stein_x3_split(const float* theta_all, const float* score_all, int64_t n, int64_t d, const SteinLayout& L,
-                   char* planes, hipStream_t stream) {
+int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
+                   const SteinLayout& L, char* planes, hipStream_t stream) {
   u16* T3 = reinterpret_cast<u16*>(planes + L.x3_t3);
   u16* Tt3 = reinterpret_cast<u16*>(planes + L.x3_tt3);
   u16* Gt3 = reinterpret_cast<u16*>(planes + L.x3_gt3);
   const int64_t rows = L.x3_rows > L.x3_nk ? L.x3_rows : L.x3_nk;   // particle extent to cover (both multiples of 32)
   const int64_t cols = L.x3_dk > L.x3_dc ? L.x3_dk : L.x3_dc;      // parameter extent
   const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-  hipLaunchKernelGGL(k_split3, grid, dim3(256), 0, stream, theta_all, (int)n, (int)d, T3, (long)L.x3_rows,
-                     (int)L.x3_dk, Tt3, (int)L.x3_dc, (long)L.x3_nk);
-  LAUNCH_CHECK("k_split3(theta)");
   const dim3 grid_g((unsigned)((L.x3_dc + 63) / 64), (unsigned)((L.x3_nk + 63) / 64));
-  hipLaunchKernelGGL(k_split3, grid_g, dim3(256), 0, stream, score_all, (int)n, (int)d, (u16*)nullptr, 0l, 32, Gt3,
-                     (int)L.x3_dc, (long)L.x3_nk);
+  if (dtype == STEIN_BF16) {
+    hipLaunchKernelGGL(k_split3<u16>, grid, dim3(256), 0, stream, (const u16*)theta_all, (int)n, (int)d, T3,
+                       (long)L.x3_rows, (int)L.x3_dk, Tt3, (int)L.x3_dc, (long)L.x3_nk);
+    LAUNCH_CHECK("k_split3(theta)");
+    hipLaunchKernelGGL(k_split3<u16>, grid_g, dim3(256), 0, stream, (const u16*)score_all, (int)n, (int)d,
+                       (u16*)nullptr, 0l, 32, Gt3, (int)L.x3_dc, (long)L.x3_nk);
+  } else {
+    hipLaunchKernelGGL(k_split3<float>, grid, dim3(256), 0, stream, (const float*)theta_all, (int)n, (int)d, T3,
+                       (long)L.x3_rows, (int)L.x3_dk, Tt3, (int)L.x3_dc, (long)L.x3_nk);
+    LAUNCH_CHECK("k_split3(theta)");
+    hipLaunchKernelGGL(k_split3<float>, grid_g, dim3(256), 0, stream, (const float*)score_all, (int)n, (int)d,
+                       (u16*)nullptr, 0l, 32, Gt3, (int)L.x3_dc, (long)L.x3_nk);
+  }
   LAUNCH_CHECK("k_split3(score)");
   return STEIN_OK;
 }
 
-int stein_x3_distance(const char* planes, const SteinLayout& L, const float* r_all, float* dist_out, int64_t n,
-                      int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
+template <bool SYM, int NP>
+static void launch_distance_x3(long nblk, hipStream_t stream, const u16* T3, int ntk, const float* r, float* D, int n,
+                               int row0, int n_local, long ld, int tiles_m, int tiles_n, u64* hist0) {
+  hipLaunchKernelGGL((k_distance_x3<SYM, NP>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r, D, n, row0,
+                     n_local, ld, tiles_m, tiles_n, hist0);
+}
+
+int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
+                      int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
                       hipStream_t stream) {
   (void)d;
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
@@ -505,25 +535,29 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, const float* r_a
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
   if (row0 + (int64_t)tiles_m * BM > L.x3_rows) return stein_fail(STEIN_E_SHAPE, "row block exceeds the padded planes");
   const long nblk = symmetric ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
-  if (symmetric)
-    hipLaunchKernelGGL((k_distance_x3<true>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r_all, dist_out,
-                       (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
-  else
-    hipLaunchKernelGGL((k_distance_x3<false>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r_all, dist_out,
-                       (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
+  const bool one = dtype == STEIN_BF16;
+  if (symmetric && one) launch_distance_x3<true, 1>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
+  else if (symmetric) launch_distance_x3<true, 3>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
+  else if (one) launch_distance_x3<false, 1>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
+  else launch_distance_x3<false, 3>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
   LAUNCH_CHECK("k_distance_x3");
   return STEIN_OK;
 }
 
-int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L,
+int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L, int dtype,
                               const float* h2_dev, float* OG, float* OT, float* RS, int64_t n, int64_t d,
                               int64_t n_local, hipStream_t stream) {
   const u16* Tt3 = reinterpret_cast<const u16*>(planes + L.x3_tt3);
   const u16* Gt3 = reinterpret_cast<const u16*>(planes + L.x3_gt3);
   const long nblk = (long)L.tiles_m * L.cblocks * L.split;
-  hipLaunchKernelGGL(k_phi_x3ws, dim3((unsigned)nblk), dim3(WS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
-                     (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
-                     (int)L.cblocks, (int)L.split, (int)L.jchunk);
+  if (dtype == STEIN_BF16)
+    hipLaunchKernelGGL(k_phi_x3ws<1>, dim3((unsigned)nblk), dim3(WS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
+                       (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
+                       (int)L.cblocks, (int)L.split, (int)L.jchunk);
+  else
+    hipLaunchKernelGGL(k_phi_x3ws<3>, dim3((unsigned)nblk), dim3(WS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
+                       (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
+                       (int)L.cblocks, (int)L.split, (int)L.jchunk);
   LAUNCH_CHECK("k_phi_x3ws");
   return STEIN_OK;
 }

@@ -78,13 +78,20 @@ __device__ __forceinline__ float comp(const float4& v, int t) {
 // ------------------------------------------------------------------------------------------------
 // k_rownorms: one wave per row
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rownorms(const float* __restrict__ T, int n, int d, float* __restrict__ r) {
+__device__ __forceinline__ float elem_f32(const float* p) { return *p; }
+__device__ __forceinline__ float elem_f32(const unsigned short* p) { return __uint_as_float((u32)*p << 16); }  // bf16 bits
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_rownorms(const TIN* __restrict__ T, int n, int d, float* __restrict__ r) {
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= n) return;
-  const float* row = T + (size_t)wave * d;
+  const TIN* row = T + (size_t)wave * d;
   float s = 0.f;
-  for (int k = lane; k < d; k += 64) s = fmaf(row[k], row[k], s);
+  for (int k = lane; k < d; k += 64) {
+    const float x = elem_f32(row + k);
+    s = fmaf(x, x, s);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) r[wave] = s;
@@ -419,8 +426,9 @@ __global__ __launch_bounds__(NTHREADS) void k_phi_partial(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // k_phi_finish: sum the split partials, form phi, per-block partial |phi|^2 in fp64
 // ------------------------------------------------------------------------------------------------
+template <typename TIN>
 __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG, const float* __restrict__ OT,
-                                                    const float* __restrict__ RS, const float* __restrict__ T,
+                                                    const float* __restrict__ RS, const TIN* __restrict__ T,
                                                     const float* __restrict__ h2p, float* __restrict__ phi,
                                                     float* __restrict__ dK, double* __restrict__ sqpart, int n, int d,
                                                     int row0, int n_local, int split) {
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
       ot += OT[z * zs + e];
       rs += RS[(size_t)z * n_local + i];
     }
-    const float th = T[(size_t)row0 * d + e];
+    const float th = elem_f32(T + (size_t)row0 * d + e);
     const float dk = (rs * th - ot) / h2;
     const float ph = (og + dk) / fn;
     phi[e] = ph;
@@ -616,25 +624,28 @@ extern "C" int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int
   return STEIN_OK;
 }
 
-extern "C" int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, void* x3_planes,
-                                size_t planes_bytes, void* stream) {
+extern "C" int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, int dtype,
+                                void* x3_planes, size_t planes_bytes, void* stream) {
   if (!theta_all || !score_all || !x3_planes) return fail(STEIN_E_BADARG, "NULL pointer");
   SteinLayout L;
-  int rc = stein_make_layout(n, n, d, STEIN_F32, STEIN_FLAG_X3, &L);
+  int rc = stein_make_layout(n, n, d, dtype, STEIN_FLAG_X3, &L);
   if (rc) return rc;
   if (planes_bytes < L.total - L.off[STEIN_WS_PLANES])
     return fail(STEIN_E_WORKSPACE, "planes buffer %zu < %zu bytes", planes_bytes, L.total - L.off[STEIN_WS_PLANES]);
-  return stein_x3_split((const float*)theta_all, (const float*)score_all, n, d, L, (char*)x3_planes,
-                        (hipStream_t)stream);
+  return stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)x3_planes, (hipStream_t)stream);
 }
 
 extern "C" int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float* r_out, void* stream) {
   if (!theta_all || !r_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (n < 1 || d < 1) return fail(STEIN_E_SHAPE, "bad shape");
-  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "rownorms: dtype %d", dtype);
+  if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "rownorms: dtype %d", dtype);
   const int blocks = (int)((n + 3) / 4);
-  hipLaunchKernelGGL(k_rownorms, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta_all, (int)n,
-                     (int)d, r_out);
+  if (dtype == STEIN_BF16)
+    hipLaunchKernelGGL(k_rownorms<unsigned short>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)theta_all, (int)n, (int)d, r_out);
+  else
+    hipLaunchKernelGGL(k_rownorms<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)theta_all,
+                       (int)n, (int)d, r_out);
   LAUNCH_CHECK("k_rownorms");
   return STEIN_OK;
 }
@@ -652,7 +663,8 @@ extern "C" int stein_distance_block(const void* theta_all, const float* r_all, i
   if ((!theta_all && !x3_planes) || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (n < 1 || d < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   if (ld_dist < n || (ld_dist & 3)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 4");
-  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "distance: dtype %d", dtype);
+  if (dtype != STEIN_F32 && !(dtype == STEIN_BF16 && x3_planes))
+    return fail(STEIN_E_UNSUPPORTED, "distance: dtype %d (bf16 inputs need the operand planes)", dtype);
   const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
   if (sym && (row0 != 0 || n_local != n || (ld_dist & 63)))
     return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs the whole matrix (row0 = 0, n_local = n) and ld_dist %% 64 == 0");
@@ -665,7 +677,7 @@ extern "C" int stein_distance_block(const void* theta_all, const float* r_all, i
     SteinLayout L;
     int rc = stein_make_layout(n_local, n, d, dtype, STEIN_FLAG_X3, &L);
     if (rc) return rc;
-    return stein_x3_distance((const char*)x3_planes, L, r_all, dist_out, n, d, row0, n_local, ld_dist, h0, sym, s);
+    return stein_x3_distance((const char*)x3_planes, L, dtype, r_all, dist_out, n, d, row0, n_local, ld_dist, h0, sym, s);
   }
   const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
   const float* T = (const float*)theta_all;
@@ -745,7 +757,8 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
                                       size_t ws_bytes, void* stream) {
   if (!dist || (!x3_planes && (!theta_all || !score_all)) || !h2_dev || !workspace)
     return fail(STEIN_E_BADARG, "NULL pointer");
-  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
+  if (dtype != STEIN_F32 && !(dtype == STEIN_BF16 && x3_planes))
+    return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d (bf16 inputs need the operand planes)", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   SteinLayout L;
   int rc = stein_make_layout(n_local, n, d, dtype, x3_planes ? STEIN_FLAG_X3 : 0, &L);
@@ -762,7 +775,7 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
   const long nblk = (long)L.tiles_m * 2 * L.cblocks * L.split;
   if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
   if (x3_planes)
-    return stein_x3_contract_partial(dist, ld_dist, (const char*)x3_planes, L, h2_dev, OG, OT, RS, n, d, n_local, s);
+    return stein_x3_contract_partial(dist, ld_dist, (const char*)x3_planes, L, dtype, h2_dev, OG, OT, RS, n, d, n_local, s);
   const bool vec = (d % 4 == 0) && (((uintptr_t)T & 15) == 0) && (((uintptr_t)G & 15) == 0);
   if (vec)
     hipLaunchKernelGGL(k_phi_partial<true>, dim3((unsigned)nblk), dim3(NTHREADS), 0, s, dist, (long)ld_dist, G, T,
@@ -780,7 +793,7 @@ extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d
                                      int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
                                      float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
   if (!theta_all || !h2_dev || !phi_local || !sqnorm_out || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
-  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
+  if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   SteinLayout L;
   int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
@@ -792,8 +805,14 @@ extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d
   const float* RS = (const float*)(ws + L.off[STEIN_WS_PART_RS]);
   double* SQ = (double*)(ws + L.off[STEIN_WS_SQPART]);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_phi_finish, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS, (const float*)theta_all,
-                     h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local, (int)L.split);
+  if (dtype == STEIN_BF16)
+    hipLaunchKernelGGL(k_phi_finish<unsigned short>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
+                       (const unsigned short*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0,
+                       (int)n_local, (int)L.split);
+  else
+    hipLaunchKernelGGL(k_phi_finish<float>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
+                       (const float*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local,
+                       (int)L.split);
   LAUNCH_CHECK("k_phi_finish");
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, SQ, (int)L.sq_blocks, sqnorm_out);
   LAUNCH_CHECK("k_sum_partials");
@@ -821,7 +840,8 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   SteinLayout L;
   int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
   if (rc) return rc;
-  if (dtype != STEIN_F32) return fail(STEIN_E_UNSUPPORTED, "svgd_phi: dtype %d not built yet", dtype);
+  if (dtype == STEIN_BF16 && !(flags & STEIN_FLAG_X3))
+    return fail(STEIN_E_UNSUPPORTED, "bf16 inputs run on the bf16-MFMA kernels: pass STEIN_FLAG_X3");
   if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
   char* ws = (char*)workspace;
   float* r = (float*)(ws + L.off[STEIN_WS_ROWNORM]);
@@ -833,7 +853,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   // level-0 histogram taken in its epilogue, levels 1-2 read the upper triangle only
   const int sf = STEIN_STAGE_SYMMETRIC;
   if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
-  if (planes && (rc = stein_x3_prepare(theta_all, score_all, n, d, planes, L.total - L.off[STEIN_WS_PLANES], stream)))
+  if (planes && (rc = stein_x3_prepare(theta_all, score_all, n, d, dtype, planes, L.total - L.off[STEIN_WS_PLANES], stream)))
     return rc;
   if ((rc = stein_median_begin(hist, sel, n * n, stream))) return rc;
   if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream)))

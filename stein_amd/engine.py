@@ -26,6 +26,15 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _dt(t):
+    """C-ABI element code of an input tensor (theta / score): fp32, or bf16 for BASELINE config 2."""
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    raise ValueError("theta / score must be float32 or bfloat16 tensors, got %s" % t.dtype)
+
+
 def _stream(t):
     if t.is_cuda:
         return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -42,17 +51,17 @@ class HipStages:
         return _lib.workspace_layout(n_local, n, d, _lib.F32, flags)
 
     def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws, flags=0):
-        _lib.call("stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _lib.F32, _ptr(phi), _ptr(h2), _ptr(sqnorm),
+        _lib.call("stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _dt(T), _ptr(phi), _ptr(h2), _ptr(sqnorm),
                   _ptr(K), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
     def x3_prepare(self, T, G, n, d, planes):
-        _lib.call("stein_x3_prepare", _ptr(T), _ptr(G), n, d, _ptr(planes), planes.numel(), _stream(T))
+        _lib.call("stein_x3_prepare", _ptr(T), _ptr(G), n, d, _dt(T), _ptr(planes), planes.numel(), _stream(T))
 
     def rownorms(self, T, n, d, r):
-        _lib.call("stein_rownorms", _ptr(T), n, d, _lib.F32, _ptr(r), _stream(T))
+        _lib.call("stein_rownorms", _ptr(T), n, d, _dt(T), _ptr(r), _stream(T))
 
     def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None):
-        _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _lib.F32, _ptr(D), ld, _ptr(hist0),
+        _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
                   _ptr(planes), _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
 
     def median_begin(self, hist, sel, total):
@@ -69,11 +78,11 @@ class HipStages:
         _lib.call("stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
 
     def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None):
-        _lib.call("stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _lib.F32, _ptr(h2),
+        _lib.call("stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _dt(T), _ptr(h2),
                   _ptr(planes), _ptr(ws), ws.numel(), _stream(D))
 
     def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, flags=0):
-        _lib.call("stein_contract_finish", _ptr(T), n, d, row0, n_local, _lib.F32, _ptr(h2), _ptr(phi),
+        _lib.call("stein_contract_finish", _ptr(T), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi),
                   _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
     def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
@@ -93,14 +102,19 @@ class SvgdEngine:
               (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
     """
 
-    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None):
+    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32):
         self.n, self.d = int(n), int(d)
+        # dtype of the theta / score tensors handed to compute_phi: float32, or bfloat16 (BASELINE config 2: the
+        # values are used as they are, K is rounded to bf16, one bf16 MFMA per product, fp32 accumulation)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be torch.float32 or torch.bfloat16")
+        self.dtype = dtype
         # x3 (default): both GEMMs run on the bf16 matrix cores with every fp32 operand split into three bf16
         # terms -- fp32-level accuracy at a fraction of the fp32-MFMA time.  x3=False (or STEIN_X3=0) selects the
         # fp32-input MFMA kernels (an exact k-ordered fmaf chain).
         if x3 is None:
             x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
-        self.x3 = bool(x3)
+        self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
         self.flags = _lib.FLAG_X3 if self.x3 else 0
         self.device = torch.device(device)
         self.stages = stages if stages is not None else HipStages()
@@ -127,8 +141,8 @@ class SvgdEngine:
         self.median = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
         if self.world > 1:
-            self.T_all = torch.empty(self.n, self.d, dtype=torch.float32, device=dev)
-            self.G_all = torch.empty(self.n, self.d, dtype=torch.float32, device=dev)
+            self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
+            self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
 
     # views into the workspace -------------------------------------------------------------
     def _section(self, sec, nbytes, dtype):
@@ -173,9 +187,9 @@ class SvgdEngine:
         """
         st, n, d, nl = self.stages, self.n, self.d, self.n_local
         for name, t in (("theta", theta_local), ("score", score_local)):
-            if tuple(t.shape) != (nl, d) or t.dtype != torch.float32 or not t.is_contiguous():
-                raise ValueError("%s must be a contiguous float32 [%d, %d] tensor, got %s %s" %
-                                 (name, nl, d, tuple(t.shape), t.dtype))
+            if tuple(t.shape) != (nl, d) or t.dtype != self.dtype or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous %s [%d, %d] tensor, got %s %s" %
+                                 (name, self.dtype, nl, d, tuple(t.shape), t.dtype))
         if self.world == 1 and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
                         self.flags)

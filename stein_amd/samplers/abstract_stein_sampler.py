@@ -28,7 +28,7 @@ class AbstractSteinSampler:
     INIT_SCALE = 0.01  # abstract_stein_sampler.py:72
 
     def __init__(self, n_particles, log_p, theta=None, *, model_vars=None, device="cuda", dtype=torch.float32,
-                 group=None, seed=None):
+                 group=None, seed=None, kernel_dtype=torch.float32, x3=None):
         """
         n_particles : total number of particles n (across all ranks).
         log_p       : see SteinSampler.
@@ -39,6 +39,9 @@ class AbstractSteinSampler:
         dtype       : storage type of particles and optimizer state: float32 (device-native) or float64 (the
                       reference's host dtype; the kernel path still runs in fp32 exactly as the reference's
                       fp32 placeholders do, stein/kernels/abstract_kernel.py:31).
+        kernel_dtype: torch.float32 (default) or torch.bfloat16 -- what theta and the score are rounded to when they
+                      are fed to the kernel / contraction (the reference rounds fp64 -> fp32 at that point).
+        x3          : None (default: split-bf16 GEMMs) / False (fp32-input MFMA GEMMs); see engine.SvgdEngine.
         """
         self.n_particles = int(n_particles)
         self.log_p = log_p
@@ -88,9 +91,11 @@ class AbstractSteinSampler:
             raise ValueError("theta must pack to [%d, d], got %s" % (self.n_local, tuple(packed.shape)))
         self.theta_matrix = packed.to(device=self.device, dtype=dtype).contiguous()
         self.n_params = self.theta_matrix.shape[1]
-        self.engine = SvgdEngine(self.n_particles, self.n_params, device=self.device, group=group)
-        self._theta32 = (self.theta_matrix if dtype == torch.float32 else
-                         torch.empty(self.n_local, self.n_params, dtype=torch.float32, device=self.device))
+        self.kernel_dtype = kernel_dtype
+        self.engine = SvgdEngine(self.n_particles, self.n_params, device=self.device, group=group, x3=x3,
+                                 dtype=kernel_dtype)
+        self._theta32 = (self.theta_matrix if dtype == kernel_dtype else
+                         torch.empty(self.n_local, self.n_params, dtype=kernel_dtype, device=self.device))
 
     # -- particle access ---------------------------------------------------------------------------
     @property
@@ -101,7 +106,7 @@ class AbstractSteinSampler:
         return convert_array_to_dictionary(self.theta_matrix, self._access, self._shapes)
 
     def _theta_f32(self):
-        if self.dtype == torch.float64:
+        if self.dtype != self.kernel_dtype:
             self._theta32.copy_(self.theta_matrix)  # the reference's fp64 -> fp32 feed (squared_exponential_kernel.py:27)
         return self._theta32
 
@@ -113,7 +118,7 @@ class AbstractSteinSampler:
             g = torch.from_numpy(np.ascontiguousarray(np.asarray(g, dtype=np.float64)))
         if tuple(g.shape) != (self.n_local, self.n_params):
             raise ValueError("score must be [%d, %d], got %s" % (self.n_local, self.n_params, tuple(g.shape)))
-        return g.to(device=self.device, dtype=torch.float32).contiguous()
+        return g.to(device=self.device, dtype=self.kernel_dtype).contiguous()
 
     # -- the hot path ---------------------------------------------------------------------------------
     def compute_phi(self, theta_array, grads_array):
@@ -123,7 +128,7 @@ class AbstractSteinSampler:
         """
         was_numpy = not isinstance(theta_array, torch.Tensor)
         T = theta_array if not was_numpy else torch.from_numpy(np.ascontiguousarray(np.asarray(theta_array, dtype=np.float64)))
-        T = T.to(device=self.device, dtype=torch.float32).contiguous()
+        T = T.to(device=self.device, dtype=self.kernel_dtype).contiguous()
         G = self._score_to_device(grads_array)
         phi = self.engine.compute_phi(T, G)
         return phi.double().cpu().numpy() if was_numpy else phi.clone()
