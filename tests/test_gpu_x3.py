@@ -111,9 +111,10 @@ def test_x3_error_is_fp32_level_at_c2_size(cuda):
     assert e[True] <= 1e-5 and e[True] <= 4 * e[False] + 1e-7, e
 
 
-def test_x3_row_blocks_match_full(cuda):
-    """Non-symmetric row blocks (the multi-rank shape) against the symmetric full run: same h2, phi to rounding."""
-    n, d, parts = 1024, 96, 4
+@pytest.mark.parametrize("n,d,parts", [(1024, 96, 4), (1000, 70, 2), (1110, 33, 3)])
+def test_x3_row_blocks_match_full(cuda, n, d, parts):
+    """Non-symmetric row blocks (the multi-rank shape) against the symmetric full run: same h2, phi to rounding.
+    The ragged cases put row0 off the 128-row tile grid, so a block's operand tiles straddle two row blocks of T3."""
     T64, G64 = _inputs(n, d, 9)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
