@@ -104,7 +104,7 @@ class NumpyStages:
     def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None):
         t, rr = T.numpy(), r.numpy()
         blk = rr[row0:row0 + n_local, None] + rr[None, :] - np.float32(2) * (t[row0:row0 + n_local] @ t.T)
-        D.numpy()[:, :n] = blk
+        D.numpy()[:n_local, :n] = blk
         if hist0 is not None:      # the HIP kernel takes the level-0 counts from its accumulators
             hist_pass(blk, 0, self._st, hist0.numpy())
 

@@ -40,6 +40,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// ---- layout of the distance block -------------------------------------------------------------------
+// D is stored tile-major: tile (I, J) = rows [128 I, 128 I + 128) x columns [32 J, 32 J + 32) of the block is one
+// contiguous [128][32] fp32 array (16 KB) at ((I * ntc + J) * 4096) floats, ntc = ld / 32 column tiles per row block
+// (ld = the column count padded to 64, the `ld_dist` of the C ABI; rows are padded to a multiple of 128).
+// Every reader of D (histogram passes, the contraction's producers) works tile by tile, so each of their wave-wide
+// loads is one 1 KB burst; with row-major rows 4 ld bytes apart a 128 x 32 tile was 128 separate cache-line visits
+// and its loads cost three times as much issue time per byte as the operand-plane loads.
+constexpr int DT_ROWS = 128, DT_COLS = 32, DT_ELEMS = DT_ROWS * DT_COLS;
+__host__ __device__ __forceinline__ size_t d_index(long row, long col, long ntc) {
+  return ((size_t)(row >> 7) * ntc + (col >> 5)) * DT_ELEMS + (row & 127) * DT_COLS + (col & 31);
+}
+
 __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -128,6 +140,7 @@ template <bool MIRROR, bool PRED, bool DIAG, bool HIST>
 __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int row0, int n_local, long ldD,
                                                        int tile_m, int brow0, u32 base, u64& packed) {
+  const long ntc = ldD >> 5;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const int l31 = lane & 31, h4 = (lane >> 5) * 4;
@@ -152,8 +165,8 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
           if (DIAG) w = lrow < col ? 2u : (lrow == col ? 1u : 0u);
           if (PRED && !(cok && rok)) w = 0u;
           if ((!PRED && !DIAG) || w) {
-            D[(size_t)lrow * ldD + col] = v[q];
-            if (DIAG && w == 2u) D[(size_t)col * ldD + lrow] = v[q];
+            D[d_index(lrow, col, ntc)] = v[q];
+            if (DIAG && w == 2u) D[d_index(col, lrow, ntc)] = v[q];
             if (HIST) {
               const u32 dg = f32_key(v[q]) >> 21;
               const u32 off = dg - base;
@@ -162,10 +175,10 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
             }
           }
         }
-        // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (16-byte aligned: ldD % 64 == 0,
-        // lrow4 % 4 == 0).  Entries past n land in the row's padding, which no later stage reads.
+        // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (lrow4 % 4 == 0: they stay inside
+        // one 32-column tile, 16-byte aligned).  Entries past n land in padding, which no later stage reads.
         if (MIRROR && cok && (!PRED || lrow4 < n_local))
-          *reinterpret_cast<float4*>(D + (size_t)col * ldD + lrow4) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(D + d_index(col, lrow4, ntc)) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }

@@ -326,12 +326,15 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
       pv[hh] = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E);
     }
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
-    // D rows are clamped to the block (rows past n_local only feed accumulator rows that are never stored)
+    // the D tile (tile_m, j0 / 32) is one contiguous [128][32] block of the tile-major distance image (rows past
+    // n_local exist as padding and only feed accumulator rows that are never stored)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) doff[p] = (u32)min(i0 + lr + 32 * p, n_local - 1) * (u32)ldD + (u32)lc;
+    for (int p = 0; p < 4; ++p) doff[p] = (u32)((lr + 32 * p) * DT_COLS + lc);
+    const float* __restrict__ drow = D + (size_t)tile_m * (ldD >> 5) * DT_ELEMS;
     auto issue_loads = [&](int j0, float4 (&rd)[4], u32x4 (&rv0)[6], u32x4 (&rv1)[6]) {
+      const float* tile = drow + (size_t)(j0 >> 5) * DT_ELEMS;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(D + j0 + doff[p]);
+      for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(tile + doff[p]);
       const size_t toff = (size_t)(j0 >> 5) * 3 * XTILE_E;
       vt3_load<NP>(pv[0] + toff, pt, rv0);
       vt3_load<NP>(pv[1] + toff, pt, rv1);

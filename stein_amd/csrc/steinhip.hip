@@ -200,35 +200,42 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
   const u32 pa = st->prefix[0], pb = st->prefix[1];
   const bool two = st->diverged != 0u;
   const int lane = threadIdx.x & 63;
-  const int segs = (n + 1023) / 1024;
-  const long units = (long)n_local * segs;
-  // unit u = (segment, row), segment-major, so a block's stride-gridDim walk samples rows evenly in every
-  // segment (with SYM the work per row shrinks towards the bottom of the matrix)
+  // one unit = one [128][32] tile of the tile-major block (16 KB, 4 x 16 B per thread); SYM skips the tiles that lie
+  // entirely below the diagonal
+  const long ntc = ldD >> 5;
+  const int ntr = (n_local + DT_ROWS - 1) / DT_ROWS, ncol_tiles = (n + DT_COLS - 1) / DT_COLS;
+  const long units = (long)ntr * ncol_tiles;
   for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const int seg = (int)(u / n_local);
-    const int row = (int)(u - (long)seg * n_local);
-    if (SYM && (seg + 1) * 1024 <= row) continue;  // the whole segment lies left of the diagonal
-    const int c0 = seg * 1024 + threadIdx.x * 4;
-    float4 v = ld4_or_zero(D + (size_t)row * ldD + c0, c0 < n && (!SYM || c0 + 3 >= row));
-    const float x[4] = {v.x, v.y, v.z, v.w};
+    const int ti = (int)(u / ncol_tiles), tj = (int)(u - (long)ti * ncol_tiles);
+    if (SYM && tj * DT_COLS + DT_COLS <= ti * DT_ROWS) continue;
+    const float* tile = D + ((size_t)ti * ntc + tj) * DT_ELEMS;
+    float4 v4[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int col = c0 + e;
-      const bool inb = col < n && (!SYM || col >= row);
-      const u32 key = f32_key(x[e]);
-      const u32 w = (SYM && col != row) ? 2u : 1u;
-      if (LEVEL == 0) {
-        if (SYM) {
-          hist_add(h, key >> 21, inb && col != row, lane, 2u);
-          if (inb && col == row) atomicAdd(&h[key >> 21], 1u);
+    for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const float4*>(tile + (threadIdx.x + 256 * q) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = threadIdx.x + 256 * q;          // float4 index inside the tile: row f / 8, columns 4 (f & 7) ..
+      const int row = ti * DT_ROWS + (f >> 3), c0 = tj * DT_COLS + (f & 7) * 4;
+      const float x[4] = {v4[q].x, v4[q].y, v4[q].z, v4[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = c0 + e;
+        const bool inb = row < n_local && col < n && (!SYM || col >= row);
+        const u32 key = f32_key(x[e]);
+        const u32 w = (SYM && col != row) ? 2u : 1u;
+        if (LEVEL == 0) {
+          if (SYM) {
+            hist_add(h, key >> 21, inb && col != row, lane, 2u);
+            if (inb && col == row) atomicAdd(&h[key >> 21], 1u);
+          } else {
+            hist_add(h, key >> 21, inb, lane);
+          }
         } else {
-          hist_add(h, key >> 21, inb, lane);
+          const u32 digit = LEVEL == 1 ? ((key >> 10) & 2047u) : (key & 1023u);
+          const u32 hi = LEVEL == 1 ? (key >> 21) : (key >> 10);
+          if (inb && hi == pa) atomicAdd(&h[digit], w);
+          if (two && inb && hi == pb) atomicAdd(&h[STEIN_HIST_BINS + digit], w);
         }
-      } else {
-        const u32 digit = LEVEL == 1 ? ((key >> 10) & 2047u) : (key & 1023u);
-        const u32 hi = LEVEL == 1 ? (key >> 21) : (key >> 10);
-        if (inb && hi == pa) atomicAdd(&h[digit], w);
-        if (two && inb && hi == pb) atomicAdd(&h[STEIN_HIST_BINS + digit], w);
       }
     }
   }
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const float* __restrict__
   const long total = (long)n_local * n;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long row = e / n, col = e - row * n;
-    K[row * ldK + col] = expf(-D[row * ldD + col] / h2 / 2.f);
+    K[row * ldK + col] = expf(-D[d_index(row, col, ldD >> 5)] / h2 / 2.f);
   }
 }
 
@@ -366,12 +373,12 @@ __global__ __launch_bounds__(NTHREADS) void k_phi_partial(const float* __restric
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
 
   float4 rd[4], rv[4];
+  // the D tile (tile_m, j0 / 32) is one contiguous [128][32] block (rows are padded to 128 in memory)
+  const float* __restrict__ drow = D + (size_t)tile_m * (ldD >> 5) * DT_ELEMS;
   auto load_d = [&](int j0) {
+    const float* tile = drow + (size_t)(j0 >> 5) * DT_ELEMS;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = i0 + lr + 32 * p;
-      rd[p] = ld4_or_zero(D + (size_t)row * ldD + j0 + lc, row < n_local && j0 + lc < jend);
-    }
+    for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(tile + (lr + 32 * p) * DT_COLS + lc);
   };
   if (jbeg < jend) {
     load_d(jbeg);
@@ -572,7 +579,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   size_t at = 0;
   auto put = [&](int sec, size_t bytes) { L->off[sec] = at; at = align_up(at + bytes, 256); };
   put(STEIN_WS_ROWNORM, (size_t)n * 4);
-  put(STEIN_WS_DIST, (size_t)n_local * L->ld_dist * 4);
+  put(STEIN_WS_DIST, align_up((size_t)n_local, DT_ROWS) * L->ld_dist * 4);   // tile-major, rows padded to 128
   put(STEIN_WS_HIST, (size_t)STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS * 8);
   put(STEIN_WS_SELECT, sizeof(SelState));
   put(STEIN_WS_PART_G, (size_t)split * n_local * d * 4);
@@ -662,7 +669,7 @@ extern "C" int stein_distance_block(const void* theta_all, const float* r_all, i
                                     const void* x3_planes, int flags, void* stream) {
   if ((!theta_all && !x3_planes) || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (n < 1 || d < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
-  if (ld_dist < n || (ld_dist & 3)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 4");
+  if (ld_dist < n || (ld_dist & 63)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 64");
   if (dtype != STEIN_F32 && !(dtype == STEIN_BF16 && x3_planes))
     return fail(STEIN_E_UNSUPPORTED, "distance: dtype %d (bf16 inputs need the operand planes)", dtype);
   const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
@@ -712,11 +719,10 @@ extern "C" int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_
                                       const void* select_state, void* hist, int flags, void* stream) {
   if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
-  if (ld_dist < n || (ld_dist & 3) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape");
+  if (ld_dist < n || (ld_dist & 31) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape (ld_dist must be a multiple of 32)");
   const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
   if (sym && n_local != n) return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs a square block");
-  const long segs = (n + 1023) / 1024;
-  long units = (long)n_local * segs;
+  const long units = ((n_local + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);   // [128][32] tiles
   const int blocks = (int)(units < 2048 ? units : 2048);
   u64* h = (u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
   const SelState* st = (const SelState*)select_state;

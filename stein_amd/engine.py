@@ -42,6 +42,22 @@ def _stream(t):
                        "stein_amd has no CPU path." % t.device)
 
 
+def untile_distances(block, n_local, n):
+    """tile-major distance image (flat [rows_padded, ld] view, tiles of [128][32]) -> row-major [n_local, n] copy"""
+    rows, ld = block.shape
+    t = block.reshape(rows // 128, ld // 32, 128, 32).permute(0, 2, 1, 3).reshape(rows, ld)
+    return t[:n_local, :n].contiguous()
+
+
+def tile_distances(matrix, ld):
+    """row-major [rows, cols] matrix -> tile-major image [rows padded to 128, ld] (zero padded), ld % 32 == 0"""
+    rows, cols = matrix.shape
+    rp = (rows + 127) // 128 * 128
+    full = torch.zeros(rp, ld, dtype=matrix.dtype, device=matrix.device)
+    full[:rows, :cols] = matrix
+    return full.reshape(rp // 128, 128, ld // 32, 32).permute(0, 2, 1, 3).contiguous().reshape(rp, ld)
+
+
 class HipStages:
     """The staged C-ABI calls on torch device tensors (the only product backend)."""
 
@@ -155,7 +171,14 @@ class SvgdEngine:
 
     @property
     def dist(self):
-        return self._section(_lib.WS_DIST, self.n_local * self.ld_dist * 4, torch.float32).view(self.n_local, self.ld_dist)
+        """The distance block as the kernels store it: tile-major, [row blocks of 128][ld/32 column tiles][128][32]
+        fp32 (flat 2-D view [rows padded to 128, ld]).  Use dist_matrix() for a row-major copy."""
+        rows = (self.n_local + 127) // 128 * 128
+        return self._section(_lib.WS_DIST, rows * self.ld_dist * 4, torch.float32).view(rows, self.ld_dist)
+
+    def dist_matrix(self):
+        """Row-major [n_local, n] copy of the distance block (de-tiled; for inspection and tests)."""
+        return untile_distances(self.dist, self.n_local, self.n)
 
     @property
     def hist(self):

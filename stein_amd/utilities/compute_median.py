@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..engine import HipStages
+from ..engine import HipStages, tile_distances
 
 
 def compute_median(D, device="cuda"):
@@ -21,9 +21,8 @@ def compute_median(D, device="cuda"):
     if t.dim() != 2 or t.numel() == 0:
         raise ValueError("compute_median expects a non-empty vector or matrix, got shape %s" % (tuple(t.shape),))
     rows, n = t.shape
-    ld = (n + 3) // 4 * 4
-    buf = torch.zeros(rows, ld, dtype=torch.float32, device=device)
-    buf[:, :n] = t.to(device=device, dtype=torch.float32)
+    ld = (n + 63) // 64 * 64
+    buf = tile_distances(t.to(device=device, dtype=torch.float32), ld)   # the select kernels read [128][32] tiles
     hist = torch.zeros(_lib.HIST_LEVELS, 2, _lib.HIST_BINS, dtype=torch.int64, device=device)
     sel = torch.zeros(64, dtype=torch.uint8, device=device)
     h2 = torch.zeros(1, dtype=torch.float32, device=device)

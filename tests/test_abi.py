@@ -35,7 +35,7 @@ def test_workspace_layout_is_consistent():
         assert all(o % 256 == 0 for o in offs)
         ld = extra[_lib.WSX_LD_DIST]
         assert ld >= n and ld % 64 == 0
-        assert offs[_lib.WS_HIST] - offs[_lib.WS_DIST] >= nl * ld * 4
+        assert offs[_lib.WS_HIST] - offs[_lib.WS_DIST] >= (nl + 127) // 128 * 128 * ld * 4   # tile-major, rows padded to 128
         assert 1 <= extra[_lib.WSX_SPLIT] <= 16
         assert extra[_lib.WSX_HIST_BINS] == _lib.HIST_BINS
     # C3 fits comfortably: D is 1 GiB, everything else < 100 MiB

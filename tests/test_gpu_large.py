@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from stein_amd.engine import SvgdEngine
+from stein_amd.engine import SvgdEngine, untile_distances
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def test_c3_full_size_properties(cuda):
     eng = SvgdEngine(n, d, device=cuda)
     dK = torch.empty(n, d, device=cuda)
     phi = eng.compute_phi(T, G, dK_out=dK).clone()
-    D = eng.dist[:, :n]
+    D = eng.dist_matrix()
     assert torch.equal(D, D.T)
     # select state: lo / hi order statistics follow the 32 bytes of ranks/prefixes/flags: floats 8..11 = median, h2, lo, hi
     st = eng.select_state.view(torch.float32)
@@ -107,12 +107,13 @@ def test_c3_row_block_equals_full(cuda):
     blocks = []
     for p in range(parts):
         ws = torch.empty(total, dtype=torch.uint8, device=cuda)
-        D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nl * ld * 4].view(torch.float32).view(nl, ld)
+        nlp = (nl + 127) // 128 * 128           # the block is stored tile-major with rows padded to 128
+        D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nlp * ld * 4].view(torch.float32).view(nlp, ld)
         r = torch.empty(n, device=cuda)
         st.rownorms(T, n, d, r)
         st.distance_block(T, r, n, d, p * nl, nl, D, ld)
         blocks.append((ws, D))
-        assert torch.equal(D[:, :n], full.dist[p * nl:(p + 1) * nl, :n])
+        assert torch.equal(untile_distances(D, nl, n), full.dist_matrix()[p * nl:(p + 1) * nl])
     hist = torch.zeros(_lib.HIST_LEVELS, 2, _lib.HIST_BINS, dtype=torch.int64, device=cuda)
     sel = torch.zeros(64, dtype=torch.uint8, device=cuda)
     h2 = torch.zeros(1, device=cuda)

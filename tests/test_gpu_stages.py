@@ -53,7 +53,7 @@ def test_stages_match_oracle(cuda, n, d):
     # rownorms + distances
     r = eng.rownorm.cpu().numpy()
     np.testing.assert_allclose(r, (T32.astype(np.float64) ** 2).sum(1), rtol=2e-6)
-    D = eng.dist[:, :n].cpu().numpy()
+    D = eng.dist_matrix().cpu().numpy()
     D64 = orc.pairwise_sq_dists(T32, np.float64)
     assert np.abs(D - D64).max() <= 4e-6 * np.abs(D64).max()
     assert np.array_equal(D, D.T), "distance block must be bitwise symmetric"
@@ -88,13 +88,13 @@ def test_fused_equals_staged(cuda, n, d):
     eng = SvgdEngine(n, d, device=cuda, x3=False)
     _staged(eng, T, G)
     phi_staged, h2_staged, sq_staged = eng.phi.clone(), eng.h2.clone(), eng.sqnorm.clone()
-    D_staged, hist_staged = eng.dist[:, :n].clone(), eng.hist.clone()
+    D_staged, hist_staged = eng.dist_matrix(), eng.hist.clone()
     eng.phi.zero_(); eng.h2.zero_(); eng.sqnorm.zero_(); eng.dist.fill_(float("nan"))
     # the fused call runs the symmetric variant (upper-triangle tiles mirrored, level-0 histogram from the
     # distance epilogue, levels 1-2 over the upper triangle with weight 2): every bit must agree
     eng.compute_phi(T, G)
     torch.cuda.synchronize()
-    assert torch.equal(eng.dist[:, :n], D_staged)
+    assert torch.equal(eng.dist_matrix(), D_staged)
     assert torch.equal(eng.hist, hist_staged)
     assert torch.equal(eng.phi, phi_staged) and torch.equal(eng.h2, h2_staged) and torch.equal(eng.sqnorm, sq_staged)
     # the marked (bench) path = staged calls with the same symmetric flags

@@ -6,7 +6,7 @@ import torch
 
 from oracle import svgd_oracle as orc
 from stein_amd import _lib
-from stein_amd.engine import SvgdEngine
+from stein_amd.engine import SvgdEngine, untile_distances
 
 pytestmark = pytest.mark.gpu
 
@@ -66,7 +66,7 @@ def test_x3_matches_oracle_and_fp32_path(cuda, n, d):
     phi = eng.compute_phi(T, G, dK_out=dK).clone()
     torch.cuda.synchronize()
 
-    D, D32 = eng.dist[:, :n], ref_eng.dist[:, :n]
+    D, D32 = eng.dist_matrix(), ref_eng.dist_matrix()
     assert torch.equal(D, D.T)                                  # symmetric by construction (mirrored tiles)
     Dn = D.cpu().numpy()
     D64 = orc.pairwise_sq_dists(T.cpu().numpy(), np.float64)
@@ -133,13 +133,14 @@ def test_x3_row_blocks_match_full(cuda, n, d, parts):
         ws = torch.empty(total, dtype=torch.uint8, device=cuda)
         planes = ws[offs[_lib.WS_PLANES]:]
         st.x3_prepare(T, G, n, d, planes)
-        D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nl * ld * 4].view(torch.float32).view(nl, ld)
+        nlp = (nl + 127) // 128 * 128           # tile-major block, rows padded to 128
+        D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nlp * ld * 4].view(torch.float32).view(nlp, ld)
         r = torch.empty(n, device=cuda)
         st.rownorms(T, n, d, r)
         st.distance_block(T, r, n, d, p * nl, nl, D, ld, hist0=hist[0], planes=planes)
         blocks.append((ws, planes, D))
         # direct vs mirrored entries may differ in the last bit (the hi*mid / mid*hi products swap order)
-        assert (D[:, :n] - full.dist[p * nl:(p + 1) * nl, :n]).abs().max().item() <= 1e-6 * full.dist[:, :n].abs().max().item()
+        assert (untile_distances(D, nl, n) - full.dist_matrix()[p * nl:(p + 1) * nl]).abs().max().item() <= 1e-6 * full.dist_matrix().abs().max().item()
     for lv in range(_lib.HIST_LEVELS):
         if lv > 0:
             for ws, planes, D in blocks:
@@ -169,7 +170,7 @@ def test_bf16_inputs_config2(cuda, n, d):
     torch.cuda.synchronize()
     Tn, Gn = T.float().cpu().numpy().astype(np.float64), G.float().cpu().numpy().astype(np.float64)
     ref = orc.svgd_step(Tn, Gn, orc.AdagradState(), np.float64)
-    D = eng.dist[:, :n].cpu().numpy()
+    D = eng.dist_matrix().cpu().numpy()
     assert np.array_equal(D, D.T)
     assert np.abs(D - ref["D"]).max() <= 4e-6 * np.abs(ref["D"]).max()
     assert abs(eng.h2.item() - ref["h2"]) <= 3e-6 * ref["h2"]
