@@ -9,8 +9,8 @@
 //
 //   k_split3        theta, score -> bf16 operand tiles ("planes", layout below)
 //   k_distance_x3   S = T T^T from the planes; shares the fp32 kernel's epilogue (D, mirror, level-0 histogram)
-//   k_phi_x3ws      warp-specialised contraction: producer waves build P = exp2(c D) (split on the fly) and stage
-//                   the V tiles, consumer waves only issue MFMAs
+//   k_phi_x3fs      warp-specialised contraction: producer waves build P = exp2(c D) (split on the fly) in LDS,
+//                   consumer waves stream the V fragments from L2 and issue the MFMAs
 //
 // Both GEMMs are "row x row" products (C[i][c] = sum_k A[i][k] B[c][k]) with k contiguous for both operands.
 //
@@ -20,8 +20,9 @@
 // 64-byte row piece its own cache-line visit: the producers spent 2900 cycles per k tile issuing loads).
 //   T3   rows = particles, k = parameters   (distance operands; rows of a tile may straddle two row blocks when a
 //        rank's row0 is not a multiple of 128, so this image is NOT pre-swizzled)
-//   Vt3  rows = parameters, k = particles   (theta^T and score^T: the contraction's B operand; tiles are always
-//        aligned, so each row's four 16-byte chunks are stored already XOR-swizzled and a tile copies to LDS verbatim)
+//   Vt3  rows = parameters, k = particles   (theta^T and score^T: the contraction's B operand; never staged in LDS:
+//        each plane of a tile is stored in MFMA fragment order [row / 32][k16 step][lane][8] (vfrag_offset), so the
+//        B fragment of a 32-column block is ONE coalesced 1 KB load, lane l reading bytes 16 l .. 16 l + 15)
 //
 // LDS image of a plane: [128 rows][64 B], chunk c of row r at 16 * (c ^ ((r >> 2) & 3)).  Conflict-free for
 //   ds_read_b128 fragments (16-lane groups {0-3,12-15,20-27}..., 64 banks): (4 row + chunk') mod 16 distinct in a group
@@ -63,6 +64,11 @@ constexpr int XPLANE = 128 * XROW;       // one 128-row plane of a tile: 8192 B
 constexpr int XOPER = 3 * XPLANE;        // three planes of one operand tile: 24576 B
 constexpr int XTILE_E = 128 * 32;        // elements of one plane of a tile
 __device__ __forceinline__ int xswz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
+// Vt3 plane, element offset of the 8 consecutive k starting at 16 ks + 8 h of row `row` (0..127): fragment order
+// [row / 32][ks][h][row % 32][8], i.e. the B fragment of (32-row block, ks) is 1 KB contiguous, lane = 32 h + row % 32
+__device__ __forceinline__ int vfrag_offset(int row, int ks, int h) {
+  return ((((row >> 5) * 2 + ks) * 2 + h) * 32 + (row & 31)) * 8;
+}
 
 // ------------------------------------------------------------------------------------------------
 // splitting
@@ -126,19 +132,20 @@ __global__ __launch_bounds__(256) void k_split3(const TIN* __restrict__ X, int n
   }
   if (!Tt) return;
   __syncthreads();
-  // transposed store: thread -> (parameter c = t >> 2, the 16 particles starting at j = row0 + 16 (t & 3)) = 2 chunks
+  // transposed store: thread -> (parameter c = t >> 2, the 16 particles starting at j = row0 + 16 (t & 3)) = the two
+  // 8-element fragments (h = 0, 1) of k16 step ks = (j & 31) >> 4, written in MFMA fragment order (vfrag_offset)
   const int c = col0 + (t >> 2), j = row0 + (t & 3) * 16;
-  if (c < dc && j < nk) {   // nk % 32 == 0 and j % 16 == 0: both chunks stay inside one k tile
-    const int rowc = c & 127, ch0 = (j & 31) >> 3;
+  if (c < dc && j < nk) {   // nk % 32 == 0 and j % 16 == 0: both fragments stay inside one k tile
+    const int rowc = c & 127, ks = (j & 31) >> 4;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       u32 w[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         w[q] = (u32)tile[s][t >> 2][(t & 3) * 16 + 2 * q] | ((u32)tile[s][t >> 2][(t & 3) * 16 + 2 * q + 1] << 16);
-      u16* base = Tt + (((size_t)(c >> 7) * ntk_t + (j >> 5)) * 3 + s) * XTILE_E + rowc * 32;
-      *reinterpret_cast<uint4*>(base + (xswz(rowc, ch0) >> 1)) = make_uint4(w[0], w[1], w[2], w[3]);
-      *reinterpret_cast<uint4*>(base + (xswz(rowc, ch0 + 1) >> 1)) = make_uint4(w[4], w[5], w[6], w[7]);
+      u16* base = Tt + (((size_t)(c >> 7) * ntk_t + (j >> 5)) * 3 + s) * XTILE_E;
+      *reinterpret_cast<uint4*>(base + vfrag_offset(rowc, ks, 0)) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(base + vfrag_offset(rowc, ks, 1)) = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
 }
@@ -253,49 +260,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_phi_x3ws: the contraction, warp-specialised.
-//   A monolithic version (every wave stages, then every wave multiplies) stalled three ways (phase stamps,
-//   STEIN_STAMPS build): its two workgroups per CU fell into lockstep (exp/split phase together, MFMA phase
-//   together), every wave blocked while its operand loads were accepted at the vector-L1 rate, and the 128-wide
-//   tile needed 40 KB of L2 traffic per 1536 MFMA cycles.  Here one 512-thread workgroup owns a 128 x 256 tile:
-//     waves 0-3  PRODUCERS  load the D tile and the V tiles, P = exp2(c D), split, fill LDS stage (it+1) & 1
-//     waves 4-7  CONSUMERS  ds_read fragments from LDS stage it & 1 and issue nothing but MFMAs (96 per k tile)
-//   Wave w and w + 4 share a SIMD, so every SIMD runs one VALU/memory wave beside one matrix wave; load
-//   back-pressure and exp latency only ever stall a producer.  One barrier per k tile hands the stages over.
+// k_phi_x3fs: the contraction, warp-specialised, V fragments streamed straight from L2.
+//   History (phase stamps, STEIN_STAMPS build): a monolithic kernel (every wave stages, then every wave multiplies)
+//   fell into lockstep phases; a producer/consumer split that staged P AND the V tiles through LDS was bound by its
+//   producers (64 KB of loads per k tile accepted at the vector-L1 rate while they also ran the exp/split VALU work).
+//   Here a 768-thread workgroup owns a 128 x 256 tile of [K.G | K.theta]:
+//     waves 0-3   PRODUCERS  load the D tile, P = exp2(c D), split into bf16 planes, fill LDS stage (it+1) & 1
+//     waves 4-11  CONSUMERS  each owns all 128 rows x 32 columns: A fragments (P) by ds_read from LDS stage it & 1,
+//                            B fragments (V) by one coalesced 1 KB global load each, issued one k tile ahead right
+//                            after the registers' last use; 48 MFMAs per k tile and wave
+//   Every SIMD holds one producer and two consumers.  V never touches LDS and is fetched exactly once per workgroup
+//   (no two waves share a B fragment).  One barrier per k tile hands the P stages over.
 //   Column space: the 128-column blocks of [G | theta] (each matrix padded to dc = roundup(d, 128)) are paired up,
-//   block cb covers pair (2cb, 2cb+1); each half picks its own source tiles and output matrix.
+//   block cb covers pair (2cb, 2cb+1); consumer wave cw takes half cw >> 2, 32-column block cw & 3.
 // ------------------------------------------------------------------------------------------------
-constexpr int WS_THREADS = 512;
-constexpr int WS_A = XOPER;            // P planes, 128 rows:            24576 B
-constexpr int WS_B = 2 * XOPER;        // V planes, two 128-row halves:  49152 B
-constexpr int WS_BUF = WS_A + WS_B;    // one pipeline stage:            73728 B  (two stages: 147456 B of the 160 KiB)
-
-// a pre-swizzled V tile (3 planes, 24 KB contiguous): thread pt copies chunks pt and pt + 256 of each plane
-template <int NP>
-__device__ __forceinline__ void vt3_load(const u16* __restrict__ tile, int pt, u32x4 (&reg)[6]) {
-#pragma unroll
-  for (int s = 0; s < NP; ++s)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      reg[s * 2 + q] = *reinterpret_cast<const u32x4*>(tile + s * XTILE_E + q * 2048 + pt * 8);
-}
-template <int NP>
-__device__ __forceinline__ void vt3_store(unsigned char* oper, int pt, const u32x4 (&reg)[6]) {
-#pragma unroll
-  for (int s = 0; s < NP; ++s)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      *reinterpret_cast<u32x4*>(oper + s * XPLANE + q * 4096 + pt * 16) = reg[s * 2 + q];
-}
+constexpr int FS_THREADS = 768;
+constexpr int FS_STAGE = XOPER;        // P planes, 128 rows: 24576 B per pipeline stage
 
 template <int NP>
-__global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restrict__ D, long ldD,
-                                                            const u16* __restrict__ Gt3, const u16* __restrict__ Tt3,
-                                                            long ntj, const float* __restrict__ h2p,
-                                                            float* __restrict__ OG, float* __restrict__ OT,
-                                                            float* __restrict__ RS, int n, int d, int n_local,
-                                                            int tiles_m, int cblocks, int split, int jchunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WS_BUF];
+__global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict__ D, long ldD,
+                                                         const u16* __restrict__ Gt3, const u16* __restrict__ Tt3,
+                                                         long ntj, const float* __restrict__ h2p,
+                                                         float* __restrict__ OG, float* __restrict__ OT,
+                                                         float* __restrict__ RS, int n, int d, int n_local,
+                                                         int tiles_m, int cblocks, int split, int jchunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FS_STAGE];
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int cb = logical % cblocks;
@@ -308,7 +297,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
 
   const int t = threadIdx.x;
   // The two roles run separate loops (so neither carries the other's registers) with the same number of
-  // barriers: one after the prologue, one per k tile.  The role test is wave-uniform (waves 0-3 / 4-7).
+  // barriers: one after the prologue, one per k tile.  The role test is wave-uniform (waves 0-3 / 4-11).
   if (t < 256) {
     // ================================ PRODUCER ================================
     const int pt = t;
@@ -317,30 +306,20 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
     // two register sets (X for even tiles, Y for odd): the loads of tile t+2 are issued as soon as tile t has been
     // turned into LDS data, so they fly during the whole production of tile t+1 and the barrier wait behind it
     float4 rdX[4], rdY[4];
-    u32x4 rvX0[6], rvX1[6], rvY0[6], rvY1[6];
     u32 doff[4];
-    const u16* __restrict__ pv[2];   // wave-uniform: first tile (k tile 0) of each half's 128-column block
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int g = 2 * cb + hh;   // 128-column block of [G | theta]
-      pv[hh] = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E);
-    }
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
     // the D tile (tile_m, j0 / 32) is one contiguous [128][32] block of the tile-major distance image (rows past
     // n_local exist as padding and only feed accumulator rows that are never stored)
 #pragma unroll
     for (int p = 0; p < 4; ++p) doff[p] = (u32)((lr + 32 * p) * DT_COLS + lc);
     const float* __restrict__ drow = D + (size_t)tile_m * (ldD >> 5) * DT_ELEMS;
-    auto issue_loads = [&](int j0, float4 (&rd)[4], u32x4 (&rv0)[6], u32x4 (&rv1)[6]) {
+    auto issue_loads = [&](int j0, float4 (&rd)[4]) {
       const float* tile = drow + (size_t)(j0 >> 5) * DT_ELEMS;
 #pragma unroll
       for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(tile + doff[p]);
-      const size_t toff = (size_t)(j0 >> 5) * 3 * XTILE_E;
-      vt3_load<NP>(pv[0] + toff, pt, rv0);
-      vt3_load<NP>(pv[1] + toff, pt, rv1);
     };
     // registers of tile j0 -> LDS stage `buf`
-    auto produce = [&](int j0, unsigned char* buf, const float4 (&rd)[4], const u32x4 (&rv0)[6], const u32x4 (&rv1)[6]) {
+    auto produce = [&](int j0, unsigned char* buf, const float4 (&rd)[4]) {
       const bool full = j0 + BK <= jend;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -374,37 +353,35 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
           *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
         }
       }
-      vt3_store<NP>(buf + WS_A, pt, rv0);
-      vt3_store<NP>(buf + WS_A + XOPER, pt, rv1);
     };
     auto jt = [&](int tile) { return jbeg + tile * BK; };   // tile index -> first column (jbeg % 32 == 0)
 #ifdef STEIN_STAMPS
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
     u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
-    if (ntile > 0) issue_loads(jt(0), rdX, rvX0, rvX1);
-    if (ntile > 1) issue_loads(jt(1), rdY, rvY0, rvY1);
+    if (ntile > 0) issue_loads(jt(0), rdX);
+    if (ntile > 1) issue_loads(jt(1), rdY);
     if (ntile > 0) {
-      produce(jt(0), smem, rdX, rvX0, rvX1);
-      if (ntile > 2) issue_loads(jt(2), rdX, rvX0, rvX1);
+      produce(jt(0), smem, rdX);
+      if (ntile > 2) issue_loads(jt(2), rdX);
     }
     __syncthreads();
     // iteration `it` (consumers are on tile it): turn tile it+1 into LDS stage (it+1)&1, then fetch tile it+3
     for (int it = 0; it < ntile; it += 2) {
       if (it + 1 < ntile) {
         STAMP(5);
-        produce(jt(it + 1), smem + WS_BUF, rdY, rvY0, rvY1);
+        produce(jt(it + 1), smem + FS_STAGE, rdY);
         STAMP(0);   // produce (includes waiting for the tile's loads)
-        if (it + 3 < ntile) issue_loads(jt(it + 3), rdY, rvY0, rvY1);
+        if (it + 3 < ntile) issue_loads(jt(it + 3), rdY);
         STAMP(1);   // issue
       }
       __syncthreads();
       STAMP(2);     // barrier
       if (it + 1 < ntile) {   // second half of the unrolled pair: consumers are on tile it+1
         if (it + 2 < ntile) {
-          produce(jt(it + 2), smem, rdX, rvX0, rvX1);
+          produce(jt(it + 2), smem, rdX);
           STAMP(0);
-          if (it + 4 < ntile) issue_loads(jt(it + 4), rdX, rvX0, rvX1);
+          if (it + 4 < ntile) issue_loads(jt(it + 4), rdX);
           STAMP(1);
         }
         __syncthreads();
@@ -431,15 +408,24 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
   } else {
     // ================================ CONSUMER ================================
     const int ct = t - 256, lane = ct & 63, cw = ct >> 6;
-    const int wy = cw >> 1, wx = cw & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    f32x16 acc[2][4];
+    const int g = 2 * cb + (cw >> 2);   // this wave's 128-column block of [G | theta]
+    // B fragments of (k tile, plane s, step ks): vb + ((kt * 3 + s) * 4096 + ks * 512) elements
+    const u16* __restrict__ vb = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E
+                                              : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E) +
+                                 (size_t)(jbeg >> 5) * 3 * XTILE_E + (cw & 3) * 1024 + lane * 8;
+    f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 b[2][3];
+    if (ntile > 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int s = 0; s < NP; ++s) b[ks][s] = *reinterpret_cast<const bf16x8*>(vb + s * XTILE_E + ks * 512);
+    }
     __syncthreads();
 #ifdef STEIN_STAMPS
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -447,25 +433,24 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
 #endif
     for (int it = 0; it < ntile; ++it) {
       STAMP(5);
-      const unsigned char* As = smem + (it & 1) * WS_BUF;
-      const unsigned char* Bs = As + WS_A + wx * XOPER;
+      const unsigned char* As = smem + (it & 1) * FS_STAGE;
+      const u16* __restrict__ vnext = vb + (size_t)(it + 1) * 3 * XTILE_E;
+      const bool more = it + 1 < ntile;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[2][3], b[4][3];
+        bf16x8 a[4][3];
         const int co = xswz(l31, 2 * ks + h);
 #pragma unroll
-        for (int s = 0; s < NP; ++s) {
+        for (int s = 0; s < NP; ++s)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            a[i][s] = *reinterpret_cast<const bf16x8*>(As + s * XPLANE + (wy * 64 + i * 32 + l31) * XROW + co);
+          for (int i = 0; i < 4; ++i)
+            a[i][s] = *reinterpret_cast<const bf16x8*>(As + s * XPLANE + (i * 32 + l31) * XROW + co);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            b[j][s] = *reinterpret_cast<const bf16x8*>(Bs + s * XPLANE + (j * 32 + l31) * XROW + co);
+        for (int i = 0; i < 4; ++i) acc[i] = x3_products<NP>(a[i], b[ks], acc[i]);
+        if (more) {   // the registers are free again: fetch the same step of the next k tile
+#pragma unroll
+          for (int s = 0; s < NP; ++s) b[ks][s] = *reinterpret_cast<const bf16x8*>(vnext + s * XTILE_E + ks * 512);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = x3_products<NP>(a[i], b[j], acc[i][j]);
       }
       STAMP(3);   // consumer: fragment reads + MFMAs
       __syncthreads();
@@ -475,21 +460,17 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_phi_x3ws(const float* __restr
     if (t == 256)
       for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
 #endif
-    const int g = 2 * cb + wx;   // this wave's 128-column block
     float* __restrict__ Oz = (g < cblocks ? OG : OT) + (size_t)z * n_local * d;
-    const int cbase = (g < cblocks ? g : g - cblocks) * BN;
+    const int col = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + l31;
+    if (col < d) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = cbase + j * 32 + l31;
-        if (col >= d) continue;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = i0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e];
+          const int row = i0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < n_local) Oz[(size_t)row * d + col] = acc[i][e];
         }
-      }
+    }
   }
 }
 
@@ -554,13 +535,13 @@ int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* pl
   const u16* Gt3 = reinterpret_cast<const u16*>(planes + L.x3_gt3);
   const long nblk = (long)L.tiles_m * L.cblocks * L.split;
   if (dtype == STEIN_BF16)
-    hipLaunchKernelGGL(k_phi_x3ws<1>, dim3((unsigned)nblk), dim3(WS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
+    hipLaunchKernelGGL(k_phi_x3fs<1>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
                        (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
                        (int)L.cblocks, (int)L.split, (int)L.jchunk);
   else
-    hipLaunchKernelGGL(k_phi_x3ws<3>, dim3((unsigned)nblk), dim3(WS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
+    hipLaunchKernelGGL(k_phi_x3fs<3>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
                        (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
                        (int)L.cblocks, (int)L.split, (int)L.jchunk);
-  LAUNCH_CHECK("k_phi_x3ws");
+  LAUNCH_CHECK("k_phi_x3fs");
   return STEIN_OK;
 }

@@ -32,14 +32,13 @@ def test_split_planes_reconstruct_fp32(cuda):
     dc, nk = (d + 127) // 128 * 128, (n + 31) // 32 * 32
     raw = eng.planes.view(torch.bfloat16)
 
-    def untile(flat, nrows, nks, swizzled):
-        """tile-major image [row blocks][k tiles][3 planes][128][32] -> summed fp32 matrix [nrows, nks]"""
-        x = flat.view(nrows // 128, nks // 32, 3, 128, 4, 8).float()
-        if swizzled:      # chunk c of row r is stored at c ^ ((r >> 2) & 3)
-            r = torch.arange(128, device=flat.device)
-            src = (torch.arange(4, device=flat.device)[None, :] ^ ((r >> 2) & 3)[:, None])       # [128, 4]
-            x = torch.gather(x, 4, src[None, None, None, :, :, None].expand_as(x))
-        return x.sum(2).permute(0, 2, 1, 3, 4).reshape(nrows, nks)
+    def untile(flat, nrows, nks, fragment_order):
+        """tile-major image [row blocks][k tiles][3 planes][one 128 x 32 plane] -> summed fp32 matrix [nrows, nks]"""
+        if fragment_order:   # plane stored as [row / 32][k16 step][h][row % 32][8] (stein_x3.hip: vfrag_offset)
+            x = flat.view(nrows // 128, nks // 32, 3, 4, 2, 2, 32, 8).float().sum(2)       # [rb, kt, q, ks, h, c, e]
+            return x.permute(0, 2, 5, 1, 3, 4, 6).reshape(nrows, nks)                      # rows (rb,q,c), k (kt,ks,h,e)
+        x = flat.view(nrows // 128, nks // 32, 3, 128, 32).float().sum(2)
+        return x.permute(0, 2, 1, 3).reshape(nrows, nks)
 
     t3 = untile(raw[:3 * rows * dk], rows, dk, False)
     off = (3 * rows * dk * 2 + 255) // 256 * 256 // 2
