@@ -34,9 +34,9 @@ def test_split_planes_reconstruct_fp32(cuda):
 
     def untile(flat, nrows, nks, fragment_order):
         """tile-major image [row blocks][k tiles][3 planes][one 128 x 32 plane] -> summed fp32 matrix [nrows, nks]"""
-        if fragment_order:   # plane stored as [row / 32][k16 step][h][row % 32][8] (stein_x3.hip: vfrag_offset)
-            x = flat.view(nrows // 128, nks // 32, 3, 4, 2, 2, 32, 8).float().sum(2)       # [rb, kt, q, ks, h, c, e]
-            return x.permute(0, 2, 5, 1, 3, 4, 6).reshape(nrows, nks)                      # rows (rb,q,c), k (kt,ks,h,e)
+        if fragment_order:   # plane stored as [row / 16][chunk][row % 16][8] (stein_x3.hip: vfrag_offset)
+            x = flat.view(nrows // 128, nks // 32, 3, 8, 4, 16, 8).float().sum(2)          # [rb, kt, q, chunk, c, e]
+            return x.permute(0, 2, 4, 1, 3, 5).reshape(nrows, nks)                         # rows (rb,q,c), k (kt,chunk,e)
         x = flat.view(nrows // 128, nks // 32, 3, 128, 32).float().sum(2)
         return x.permute(0, 2, 1, 3).reshape(nrows, nks)
 
