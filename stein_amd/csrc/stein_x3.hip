@@ -291,12 +291,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
 //                            B fragments (V) by one coalesced 1 KB global load each, issued one k tile ahead right
 //                            after the registers' last use; 48 MFMAs per k tile and wave
 //   Every SIMD holds one producer and two consumers.  V never touches LDS and is fetched exactly once per workgroup
-//   (no two waves share a B fragment).  One barrier per k tile hands the P stages over.
+//   (no two waves share a B fragment).  One barrier per pipeline stage (two k tiles) hands the P stages over.
 //   Column space: the 128-column blocks of [G | theta] (each matrix padded to dc = roundup(d, 128)) are paired up,
 //   block cb covers pair (2cb, 2cb+1); consumer wave cw takes half cw >> 2, 32-column block cw & 3.
 // ------------------------------------------------------------------------------------------------
 constexpr int FS_THREADS = 768;
-constexpr int FS_STAGE = XOPER;        // P planes, 128 rows: 24576 B per pipeline stage
+constexpr int FS_KT = 2;                   // k tiles per pipeline stage (even: tile parity picks the register set)
+constexpr int FS_STAGE = FS_KT * XOPER;    // P planes, 128 rows x 2 k tiles: 49152 B per pipeline stage (2 stages)
 
 template <int NP>
 __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict__ D, long ldD,
@@ -380,34 +381,31 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
     u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
+    // A pipeline stage holds FS_KT = 2 consecutive k tiles, so the workgroup synchronises once per two tiles.  Tile
+    // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
+    const int nstage = (ntile + FS_KT - 1) / FS_KT;
     if (ntile > 0) issue_loads(jt(0), rdX);
     if (ntile > 1) issue_loads(jt(1), rdY);
-    if (ntile > 0) {
-      produce(jt(0), smem, rdX);
-      if (ntile > 2) issue_loads(jt(2), rdX);
-    }
+    auto produce_stage = [&](int st, unsigned char* buf) {
+      const int tile = st * FS_KT;
+      if (tile < ntile) {
+        produce(jt(tile), buf, rdX);
+        if (tile + 2 < ntile) issue_loads(jt(tile + 2), rdX);
+      }
+      if (tile + 1 < ntile) {
+        produce(jt(tile + 1), buf + XOPER, rdY);
+        if (tile + 3 < ntile) issue_loads(jt(tile + 3), rdY);
+      }
+    };
+    produce_stage(0, smem);
     __syncthreads();
-    // iteration `it` (consumers are on tile it): turn tile it+1 into LDS stage (it+1)&1, then fetch tile it+3
-    for (int it = 0; it < ntile; it += 2) {
-      if (it + 1 < ntile) {
-        STAMP(5);
-        produce(jt(it + 1), smem + FS_STAGE, rdY);
-        STAMP(0);   // produce (includes waiting for the tile's loads)
-        if (it + 3 < ntile) issue_loads(jt(it + 3), rdY);
-        STAMP(1);   // issue
-      }
+    // iteration st (consumers are on stage st): fill stage st+1 into the other buffer
+    for (int st = 0; st < nstage; ++st) {
+      STAMP(5);
+      if (st + 1 < nstage) produce_stage(st + 1, smem + ((st + 1) & 1) * FS_STAGE);
+      STAMP(0);   // produce (includes waiting for the tiles' loads)
       __syncthreads();
-      STAMP(2);     // barrier
-      if (it + 1 < ntile) {   // second half of the unrolled pair: consumers are on tile it+1
-        if (it + 2 < ntile) {
-          produce(jt(it + 2), smem, rdX);
-          STAMP(0);
-          if (it + 4 < ntile) issue_loads(jt(it + 4), rdX);
-          STAMP(1);
-        }
-        __syncthreads();
-        STAMP(2);
-      }
+      STAMP(2);   // barrier
     }
 #ifdef STEIN_STAMPS
     if (t == 0) {
@@ -482,20 +480,20 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
     u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (int it = 0; it < ntile; it += 2) {
+    const int nstage = (ntile + FS_KT - 1) / FS_KT;
+    for (int st = 0; st < nstage; ++st) {
       STAMP(5);
-      if (it + 1 < ntile) load_b(it + 1, bY);
-      mma_tile(smem, bX);
+      const unsigned char* As = smem + (st & 1) * FS_STAGE;
+      const int tile = st * FS_KT;
+      if (tile + 1 < ntile) load_b(tile + 1, bY);
+      mma_tile(As, bX);
+      if (tile + 1 < ntile) {
+        if (tile + 2 < ntile) load_b(tile + 2, bX);
+        mma_tile(As + XOPER, bY);
+      }
       STAMP(3);   // consumer: fragment reads + MFMAs
       __syncthreads();
       STAMP(4);   // consumer: barrier
-      if (it + 1 < ntile) {
-        if (it + 2 < ntile) load_b(it + 2, bX);
-        mma_tile(smem + FS_STAGE, bY);
-        STAMP(3);
-        __syncthreads();
-        STAMP(4);
-      }
     }
 #ifdef STEIN_STAMPS
     if (t == 256)
