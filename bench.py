@@ -147,7 +147,7 @@ def pmc_traffic(workload_key, x3):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(workload_key, {}).get("k_phi_x3ws_hbm_bytes" if x3 else "k_phi_partial_hbm_bytes")
+            return json.load(f).get(workload_key, {}).get("k_phi_x3fs_hbm_bytes" if x3 else "k_phi_partial_hbm_bytes")
     except Exception:
         return None
 
@@ -226,7 +226,7 @@ def main():
         "element_updates_per_s": value * d,
         "pair_interactions_per_s": value * n,
         "roofline": {
-            "kernel": ("k_phi_x3ws (exp + split-bf16 MFMA K.[G|theta] contraction, 6 bf16 products per fp32 pair)"
+            "kernel": ("k_phi_x3fs (exp + split-bf16 MFMA K.[G|theta] contraction, 6 bf16 products per fp32 pair)"
                        if res["x3"] else "k_phi_partial (exp + fp32-input MFMA K.[G|theta] contraction)"),
             "bound": "mfma", "achieved": achieved / 1e12 if achieved else None, "peak": PEAK_FP32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA if achieved else None,

@@ -16,8 +16,8 @@ lib.stein_debug_stamps(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 nb = v[7]
 jt = (n + 31) // 32
-names = ["P:produce", "P:issue", "P:barrier", "C:mma", "C:barrier", "-"]
+names = ["P:produce", "P:issue", "P:barrier", "C4:mma", "C4:barrier", "C8:total", "C8:bwait"]
 print("blocks", nb, "split", eng.split, "ktiles/block", jt / eng.split)
 for k, nm in enumerate(names):
     print("%-15s %8.1f ticks per k-tile (100 MHz ticks? s_memtime = shader clock)" % (nm, v[k] / nb / (jt / eng.split)))
-print("sum", v[:6].sum() / nb / (jt / eng.split))
+

@@ -485,9 +485,16 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       STAMP(5);
       const unsigned char* As = smem + (st & 1) * FS_STAGE;
       const int tile = st * FS_KT;
+#ifdef STEIN_STAMPS
+#define BWAIT() do { STAMP(3); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(0); } while (0)
+#else
+#define BWAIT() do {} while (0)
+#endif
+      BWAIT();
       if (tile + 1 < ntile) load_b(tile + 1, bY);
       mma_tile(As, bX);
       if (tile + 1 < ntile) {
+        BWAIT();
         if (tile + 2 < ntile) load_b(tile + 2, bX);
         mma_tile(As + XOPER, bY);
       }
@@ -498,6 +505,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #ifdef STEIN_STAMPS
     if (t == 256)
       for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+    if (t == 512) {   // the second matrix wave of the same SIMD
+      atomicAdd(&g_stamps[5], st_acc[3] + st_acc[4]);
+      atomicAdd(&g_stamps[6], st_acc[0]);   // time spent waiting for the B fragments at the top of a tile
+    }
 #endif
     float* __restrict__ Oz = (g < cblocks ? OG : OT) + (size_t)z * n_local * d;
     const int cbase = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + l15;
