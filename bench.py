@@ -142,6 +142,10 @@ def cpu_baseline(wl, T64, G64, rows):
                 seconds=dt)
 
 
+# products per fp32 operand pair in the split path (stein_x3.hip: KIND 2 -> 3 fp16 products, KIND 3 -> 6 bf16 products)
+NPROD = 6 if os.environ.get("STEIN_SPLIT_KIND", "").startswith("b3") else 3
+
+
 def pmc_traffic(workload_key, x3):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/pmc_traffic.json), if any."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -226,20 +230,20 @@ def main():
         "element_updates_per_s": value * d,
         "pair_interactions_per_s": value * n,
         "roofline": {
-            "kernel": ("k_phi_x3fs (exp + split-bf16 MFMA K.[G|theta] contraction, 6 bf16 products per fp32 pair)"
-                       if res["x3"] else "k_phi_partial (exp + fp32-input MFMA K.[G|theta] contraction)"),
+            "kernel": ("k_phi_x3fs (exp + split-precision MFMA K.[G|theta] contraction, %d 16-bit products per fp32 pair)"
+                       % NPROD if res["x3"] else "k_phi_partial (exp + fp32-input MFMA K.[G|theta] contraction)"),
             "bound": "mfma", "achieved": achieved / 1e12 if achieved else None, "peak": PEAK_FP32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA if achieved else None,
             "flops_per_launch": flops, "ms_per_launch": k_ms,
             "traffic": pmc_traffic(args.workload, res["x3"]) if world == 1 else None,
             "note": ("achieved = ALGORITHMIC fp32 flops (4 n_local n d) / kernel time against the dense fp32-input MFMA "
-                     "peak, as SURVEY 7/8(d) prescribes for split-precision emulation; the kernel executes 6x that many "
-                     "bf16 MFMA flops" if res["x3"] else "fp32-input MFMA kernel"),
-            "executed_mfma_tflops": (6.0 if res["x3"] else 1.0) * achieved / 1e12 if achieved else None,
-            "frac_of_executed_dtype_peak": ((6.0 * achieved / PEAK_BF16_MFMA) if res["x3"] else achieved / PEAK_FP32_MFMA)
+                     "peak, as SURVEY 7/8(d) prescribes for split-precision emulation; the kernel executes %dx that many "
+                     "16-bit MFMA flops" % NPROD if res["x3"] else "fp32-input MFMA kernel"),
+            "executed_mfma_tflops": (NPROD if res["x3"] else 1.0) * achieved / 1e12 if achieved else None,
+            "frac_of_executed_dtype_peak": ((NPROD * achieved / PEAK_BF16_MFMA) if res["x3"] else achieved / PEAK_FP32_MFMA)
             if achieved else None,
         },
-        "gemm_path": "x3 split-bf16" if res["x3"] else "fp32 mfma",
+        "gemm_path": ("split fp16 x 2 (3 products)" if NPROD == 3 else "split bf16 x 3 (6 products)") if res["x3"] else "fp32 mfma",
         "stage_ms": {k: round(v, 4) for k, v in res["stages"].items()},
         "full_step_tflops": 6.0 * nl * n * d / (ms_per_step * 1e-3) / 1e12,
         "finite": res["finite"],

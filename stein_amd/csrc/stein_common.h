@@ -139,7 +139,7 @@ __device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane
 template <bool MIRROR, bool PRED, bool DIAG, bool HIST>
 __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int row0, int n_local, long ldD,
-                                                       int tile_m, int brow0, u32 base, u64& packed) {
+                                                       int tile_m, int brow0, u32 base, u64& packed, float two_s) {
   const long ntc = ldD >> 5;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
           const int lrow = lrow4 + q;
           const bool rok = !PRED || lrow < n_local;
           const float ri = rok ? r[row0 + lrow] : 0.f;
-          v[q] = (ri + rj) - 2.f * acc[i][j][4 * g + q];
+          v[q] = (ri + rj) - two_s * acc[i][j][4 * g + q];
           u32 w = MIRROR ? 2u : 1u;
           if (DIAG) w = lrow < col ? 2u : (lrow == col ? 1u : 0u);
           if (PRED && !(cok && rok)) w = 0u;
@@ -188,7 +188,10 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
 template <bool SYM>
 __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                   float* __restrict__ D, int n, int row0, int n_local, long ldD,
-                                                  int tile_m, int tile_n, u64* __restrict__ hist0) {
+                                                  int tile_m, int tile_n, u64* __restrict__ hist0,
+                                                  float two_s = 2.f) {
+  // two_s: D = r_i + r_j - two_s * acc.  2 for S = T T^T accumulated at full scale; the split kernels accumulate the
+  // product of operands pre-scaled by a power of two and pass 2 / scale^2 (exact either way)
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const int brow0 = tile_n * BN;
@@ -197,7 +200,7 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   if (hist0) {
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
     __syncthreads();
-    const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - 2.f * acc[0][0][0];
+    const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - two_s * acc[0][0][0];
     base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
     base = base < 3u ? 0u : base - 3u;  // window start
   }
@@ -206,9 +209,9 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
 #define STEIN_EPI(MIRROR, PRED, DIAG)                                                                                  \
   do {                                                                                                                 \
     if (hist0) distance_epilogue_body<MIRROR, PRED, DIAG, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,  \
-                                                                base, packed);                                        \
+                                                                base, packed, two_s);                                 \
     else distance_epilogue_body<MIRROR, PRED, DIAG, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0, base, \
-                                                           packed);                                                   \
+                                                           packed, two_s);                                            \
   } while (0)
   if (diag) STEIN_EPI(false, true, true);
   else if (edge) STEIN_EPI(SYM, true, false);
@@ -272,5 +275,6 @@ struct SteinLayout {
   int64_t x3_rows, x3_dk;   // row-major theta planes: x3_rows x x3_dk  (distance operands)
   int64_t x3_dc, x3_nk;     // transposed planes of theta and of the score: x3_dc x x3_nk  (contraction B operand)
   size_t x3_t3, x3_tt3, x3_gt3;  // byte offsets inside the PLANES section
+  size_t x3_sc;                  // power-of-two operand scales (stein_x3.hip: "scales area"), inside the PLANES section
 };
 int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, SteinLayout* L);

@@ -1,28 +1,36 @@
-// stein_x3.hip -- both GEMMs of the SVGD step on the bf16 matrix cores with fp32-level accuracy.
+// stein_x3.hip -- both GEMMs of the SVGD step on the 16-bit matrix cores with fp32-level accuracy.
 //
-// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of the fp32-input MFMA.  Every fp32 operand x is split
-// into three bf16 terms  x = hi + mid + lo  (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); the two
-// subtractions are exact in fp32, so the three terms carry 24 significant bits), and a product a*b is formed from
-// the six term pairs whose weight is >= 2^-16:  lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  -- the dropped
-// pairs are below 2^-24 relative.  bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so
-// the result has fp32-MFMA-level error at 6/16 of its matrix-core time.
+// gfx950 runs the 16-bit-input MFMAs at 16x the rate of the fp32-input MFMA.  Every fp32 operand x is split into a
+// short sum of 16-bit terms whose pairwise products are exact in fp32 (the MFMA accumulates in fp32), and a product
+// a*b is formed from the term pairs that matter.  KIND selects the split:
+//   KIND 2 (default, fp32 inputs)  x * 2^s = hi + lo, two fp16 terms (hi = fp16(x'), lo = fp16(x' - hi), the subtraction
+//          is exact: 22 significant bits); products lo*hi, hi*lo, hi*hi (the dropped lo*lo is 2^-22 relative).  fp16 has
+//          a 5-bit exponent, so operands are pre-scaled by powers of two (exact, undone exactly in the epilogues):
+//          theta^T and score^T per column to a column maximum in [2^13, 2^14), theta for the distance GEMM by one factor
+//          for the whole matrix, and P = exp2(c D + 14) in (0, 2^14].  An entry far below its column's maximum keeps
+//          an ABSOLUTE error of 2^-25 of the scaled unit, i.e. 2^-38 of the column maximum -- the same norm-wise
+//          guarantee an fp32 GEMM gives.
+//   KIND 3 (STEIN_SPLIT_KIND=b3)   x = hi + mid + lo, three bf16 terms (24 significant bits, no scaling needed); the six
+//          products >= 2^-16: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  Twice the matrix-core time of KIND 2.
+//   KIND 1 (bf16 inputs)           the value itself; one product.
 //
-//   k_split3        theta, score -> bf16 operand tiles ("planes", layout below)
+//   k_colmax, k_make_scales   column maxima -> power-of-two scales (KIND 2; all ones otherwise)
+//   k_split         theta, score -> 16-bit operand tiles ("planes", layout below)
 //   k_distance_x3   S = T T^T from the planes; shares the fp32 kernel's epilogue (D, mirror, level-0 histogram)
 //   k_phi_x3fs      warp-specialised contraction: producer waves build P = exp2(c D) (split on the fly) in LDS,
 //                   consumer waves stream the V fragments from L2 and issue the MFMAs
 //
 // Both GEMMs are "row x row" products (C[i][c] = sum_k A[i][k] B[c][k]) with k contiguous for both operands.
 //
-// Operand tile = 128 rows x 32 k of one plane = [128][32] bf16 = 8 KB; the three planes of a tile are adjacent
-// (24 KB) and tiles are stored tile-major:  tile(rb, kt) at ((rb * ntk + kt) * 3 + plane) * 4096 elements.
+// Operand tile = 128 rows x 32 k of one plane = [128][32] x 16 bit = 8 KB; a tile has three plane slots (24 KB, KIND of
+// them used) and tiles are stored tile-major:  tile(rb, kt) at ((rb * ntk + kt) * 3 + plane) * 4096 elements.
 // One wave-wide 16-byte-per-lane load therefore covers 1 KB of consecutive memory (row-major planes made every
 // 64-byte row piece its own cache-line visit: the producers spent 2900 cycles per k tile issuing loads).
 //   T3   rows = particles, k = parameters   (distance operands; rows of a tile may straddle two row blocks when a
 //        rank's row0 is not a multiple of 128, so this image is NOT pre-swizzled)
 //   Vt3  rows = parameters, k = particles   (theta^T and score^T: the contraction's B operand; never staged in LDS:
-//        each plane of a tile is stored in MFMA fragment order [row / 32][k16 step][lane][8] (vfrag_offset), so the
-//        B fragment of a 32-column block is ONE coalesced 1 KB load, lane l reading bytes 16 l .. 16 l + 15)
+//        each plane of a tile is stored in MFMA fragment order [row / 16][chunk][row % 16][8] (vfrag_offset), so the
+//        B fragment of a 16-column block is ONE coalesced 1 KB load, lane l reading bytes 16 l .. 16 l + 15)
 //
 // LDS image of a plane: [128 rows][64 B], chunk c of row r at 16 * (c ^ ((r >> 2) & 3)).  Conflict-free for
 //   ds_read_b128 fragments (16-lane groups {0-3,12-15,20-27}..., 64 banks): (4 row + chunk') mod 16 distinct in a group
@@ -30,13 +38,27 @@
 //   ds_write_b64 of P      (16 consecutive lanes = 2 rows x 8 half-chunks): same split
 // (an 80-byte padded row made every write 2-way conflicted.)  Lane l of a 32x32x16 MFMA reads the 8 consecutive k
 // of row (l & 31) at k offset 8 (l >> 5).
+//
+// Scales area (floats at planes + L.x3_sc; dc = roundup(d, 128)):
+//   [0, dc)       in-scale of the score columns       Gt3 = split(G * in)
+//   [dc, 2dc)     in-scale of the theta columns       Tt3 = split(theta * in)
+//   [2dc, 3dc)    out-scale of the K.G columns        = 1 / (in * 2^PEXP)
+//   [3dc, 4dc)    out-scale of the K.theta columns
+//   [4dc + 0]     in-scale of theta for T3 (one factor: S = T T^T mixes the columns)
+//   [4dc + 1]     two_s = 2 / in^2:  D = r_i + r_j - two_s * S'
+//   [4dc + 2]     2^-PEXP, the rowsum(K) unscale
+//   then u32 [2][dc]: bit patterns of the column maxima of |score|, |theta| (scratch of k_colmax)
 
 #include "stein_x3.h"
 
 #include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
+constexpr int PEXP_H2 = 14;   // KIND 2: P = exp2(c D + 14), in (0, 2^14] (fp16 normal range down to P = 2^-28)
+template <int KIND> struct SplitTraits { static constexpr int pexp = KIND == 2 ? PEXP_H2 : 0; };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // staging registers (native vector: stays in VGPRs)
 
 #ifdef STEIN_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of one wave per role and workgroup
@@ -86,6 +108,23 @@ __device__ __forceinline__ u32 cvt_pk_bf16(float lo, float hi) {   // round-to-n
   return r;
 }
 
+__device__ __forceinline__ u32 cvt_pk_f16(float lo, float hi) {    // round-to-nearest-even, lo -> bits 15:0
+  u32 r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// x - (fp16 in the low / high half of h), one instruction, exact
+__device__ __forceinline__ float f16_resid_lo(u32 h, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float f16_resid_hi(u32 h, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+
 // two fp32 values -> three packed bf16 pairs (x in the low half)
 __device__ __forceinline__ void split3_pair(float x, float y, u32& hi, u32& mid, u32& lo) {
   hi = cvt_pk_bf16(x, y);
@@ -95,6 +134,75 @@ __device__ __forceinline__ void split3_pair(float x, float y, u32& hi, u32& mid,
   lo = cvt_pk_bf16(sx, sy);
 }
 
+// two fp32 values -> KIND packed 16-bit pairs w[0..KIND) (x in the low half), most significant term first
+template <int KIND>
+__device__ __forceinline__ void split_pair(float x, float y, u32 (&w)[3]) {
+  if (KIND == 3) {
+    split3_pair(x, y, w[0], w[1], w[2]);
+  } else if (KIND == 2) {
+    w[0] = cvt_pk_f16(x, y);
+    w[1] = cvt_pk_f16(f16_resid_lo(w[0], x), f16_resid_hi(w[0], y));
+  } else {
+    w[0] = cvt_pk_bf16(x, y);   // bf16 inputs: exact
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scales (KIND 2)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ u32 abs_bits(u16 v) { return ((u32)v << 16) & 0x7fffffffu; }
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((u32)(e + 127) << 23); }   // -126 <= e <= 127
+// exponent s with  max * 2^s in [2^13, 2^14); 0 for an all-zero / subnormal / non-finite column
+__device__ __forceinline__ int scale_exp(u32 maxbits, int lim) {
+  const int E = (int)((maxbits >> 23) & 0xffu);
+  if (E == 0 || E == 255) return 0;
+  const int sft = 140 - E;
+  return sft < -lim ? -lim : (sft > lim ? lim : sft);
+}
+
+// column maxima of |X| [n][d] as bit patterns (non-negative floats order like unsigned integers)
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X, int n, int d, u32* __restrict__ cmax) {
+  __shared__ u32 red[4][64];
+  const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  u32 m = 0u;
+  if (col < d)
+    for (long r = (long)blockIdx.y * 4 + ry; r < n; r += (long)gridDim.y * 4) m = max(m, abs_bits(X[(size_t)r * d + col]));
+  red[ry][cx] = m;
+  __syncthreads();
+  if (ry == 0 && col < d) atomicMax(&cmax[col], max(max(red[0][cx], red[1][cx]), max(red[2][cx], red[3][cx])));
+}
+
+// one workgroup: maxima -> the scales area (see the header).  enable = 0 writes the neutral scales.
+__global__ __launch_bounds__(256) void k_make_scales(const u32* __restrict__ cmax, int dc, float* __restrict__ sc, int pexp,
+                                                     int enable) {
+  __shared__ u32 red[256];
+  const int t = threadIdx.x;
+  u32 m = 0u;
+  for (int c = t; c < dc; c += 256) {
+    const int sg = enable ? scale_exp(cmax[c], 100) : 0, st = enable ? scale_exp(cmax[dc + c], 100) : 0;
+    sc[c] = pow2i(sg);
+    sc[dc + c] = pow2i(st);
+    sc[2 * dc + c] = pow2i(-sg - pexp);
+    sc[3 * dc + c] = pow2i(-st - pexp);
+    m = max(m, cmax[dc + c]);
+  }
+  red[t] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = max(red[t], red[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    const int sa = enable ? scale_exp(red[0], 60) : 0;
+    sc[4 * dc + 0] = pow2i(sa);
+    sc[4 * dc + 1] = pow2i(1 - 2 * sa);
+    sc[4 * dc + 2] = pow2i(-pexp);
+  }
+}
+
 // One 64x64 tile of X [n][d] per workgroup.
 //   R  != NULL: tile-major image with rows = X rows (dk / 32 k tiles per row block), not swizzled, rows < r_rows, k < dk
 //   Tt != NULL: tile-major image with rows = X columns (nk / 32 k tiles per row block), pre-swizzled, rows < dc, k < nk
@@ -102,39 +210,45 @@ __device__ __forceinline__ void split3_pair(float x, float y, u32& hi, u32& mid,
 __device__ __forceinline__ float load_as_f32(const float* p) { return *p; }
 __device__ __forceinline__ float load_as_f32(const u16* p) { return __uint_as_float((u32)*p << 16); }   // bf16 bits
 
-// TIN = float (three planes: hi, mid, lo) or u16 = bf16 bits (the value IS the hi plane; mid = lo = 0 are written too,
-// so a bf16 image can be consumed by either kernel variant).
-template <typename TIN>
-__global__ __launch_bounds__(256) void k_split3(const TIN* __restrict__ X, int n, int d, u16* __restrict__ R,
-                                                long r_rows, int dk, u16* __restrict__ Tt, int dc, long nk) {
-  __shared__ u16 tile[3][64][66];
+// TIN = float (KIND 2 or 3) or u16 = bf16 bits (KIND 1).  sc_all scales the row-major image, sc_col[c] column c of the
+// transposed one (both powers of two; 1 unless KIND 2).
+template <typename TIN, int KIND>
+__global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X, int n, int d, u16* __restrict__ R, long r_rows,
+                                               int dk, u16* __restrict__ Tt, int dc, long nk,
+                                               const float* __restrict__ sc_all, const float* __restrict__ sc_col) {
+  __shared__ u16 tile[KIND][64][66];
   const int t = threadIdx.x;
   const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
   const int lr = t >> 4, lc = (t & 15) * 4;
   const long ntk_r = dk >> 5, ntk_t = nk >> 5;
+  const float sa = R ? *sc_all : 1.f;
+  float scq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) scq[q] = (Tt && col0 + lc + q < dc) ? sc_col[col0 + lc + q] : 1.f;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int row = row0 + lr + 16 * p, col = col0 + lc;
     float v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = (row < n && col + q < d) ? load_as_f32(X + (size_t)row * d + col + q) : 0.f;
-    u32 h0, m0, l0, h1, m1, l1;
-    split3_pair(v[0], v[1], h0, m0, l0);
-    split3_pair(v[2], v[3], h1, m1, l1);
     if (R && row < r_rows && col < dk) {   // col % 4 == 0: the 4 entries stay inside one 32-wide k tile
+      u32 wa[3], wb[3];
+      split_pair<KIND>(v[0] * sa, v[1] * sa, wa);
+      split_pair<KIND>(v[2] * sa, v[3] * sa, wb);
       u16* dst = R + (((size_t)(row >> 7) * ntk_r + (col >> 5)) * 3) * XTILE_E + (row & 127) * 32 + (col & 31);
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + XTILE_E) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(dst + 2 * XTILE_E) = make_uint2(l0, l1);
+#pragma unroll
+      for (int s = 0; s < KIND; ++s) *reinterpret_cast<uint2*>(dst + s * XTILE_E) = make_uint2(wa[s], wb[s]);
     }
     if (Tt) {
+      u32 wa[3], wb[3];
+      split_pair<KIND>(v[0] * scq[0], v[1] * scq[1], wa);
+      split_pair<KIND>(v[2] * scq[2], v[3] * scq[3], wb);
       const int rr = lr + 16 * p;
-      tile[0][lc + 0][rr] = (u16)h0; tile[0][lc + 1][rr] = (u16)(h0 >> 16);
-      tile[0][lc + 2][rr] = (u16)h1; tile[0][lc + 3][rr] = (u16)(h1 >> 16);
-      tile[1][lc + 0][rr] = (u16)m0; tile[1][lc + 1][rr] = (u16)(m0 >> 16);
-      tile[1][lc + 2][rr] = (u16)m1; tile[1][lc + 3][rr] = (u16)(m1 >> 16);
-      tile[2][lc + 0][rr] = (u16)l0; tile[2][lc + 1][rr] = (u16)(l0 >> 16);
-      tile[2][lc + 2][rr] = (u16)l1; tile[2][lc + 3][rr] = (u16)(l1 >> 16);
+#pragma unroll
+      for (int s = 0; s < KIND; ++s) {
+        tile[s][lc + 0][rr] = (u16)wa[s]; tile[s][lc + 1][rr] = (u16)(wa[s] >> 16);
+        tile[s][lc + 2][rr] = (u16)wb[s]; tile[s][lc + 3][rr] = (u16)(wb[s] >> 16);
+      }
     }
   }
   if (!Tt) return;
@@ -145,7 +259,7 @@ __global__ __launch_bounds__(256) void k_split3(const TIN* __restrict__ X, int n
   if (c < dc && j < nk) {   // nk % 32 == 0 and j % 16 == 0: both fragments stay inside one k tile
     const int rowc = c & 127, ch0 = (j & 31) >> 3;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < KIND; ++s) {
       u32 w[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q)
@@ -186,32 +300,44 @@ __device__ __forceinline__ void x3_store_swz(unsigned char* oper, int t, const u
     }
 }
 
-// the products of one fragment pair: six for the three-term split (smallest first; planes 0 = hi, 1 = mid, 2 = lo),
-// one for plain bf16 operands
+// The products of one fragment pair, smallest first (plane 0 = most significant term).  NP is the split KIND = the
+// number of planes: 3 -> six bf16 products, 2 -> three fp16 products, 1 -> one bf16 product.  Fragments are held
+// as 32-bit vectors and bit-cast at the MFMA (loop-carried 16-bit vectors get scalarised by the compiler).
+#define X3_BF(v) __builtin_bit_cast(bf16x8, v)
+#define X3_HF(v) __builtin_bit_cast(f16x8, v)
 template <int NP>
-__device__ __forceinline__ f32x16 x3_products(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-  if (NP == 3) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+__device__ __forceinline__ f32x16 x3_products(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+  if (NP == 2) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(X3_HF(a[1]), X3_HF(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(X3_HF(a[0]), X3_HF(b[1]), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(X3_HF(a[0]), X3_HF(b[0]), c, 0, 0, 0);
   }
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  if (NP == 3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[2]), X3_BF(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[1]), X3_BF(b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[1]), X3_BF(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[1]), c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[0]), c, 0, 0, 0);
 }
 
 // the same products on the 16x16x32 shape (one MFMA covers a whole 32-deep k tile)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NP>
-__device__ __forceinline__ f32x4 x3_products16(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
-  if (NP == 3) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+__device__ __forceinline__ f32x4 x3_products16(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+  if (NP == 2) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[1]), X3_HF(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[0]), X3_HF(b[1]), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[0]), X3_HF(b[0]), c, 0, 0, 0);
   }
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  if (NP == 3) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[2]), X3_BF(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[1]), X3_BF(b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[1]), X3_BF(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[1]), c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[0]), c, 0, 0, 0);
 }
 
 // one 32-deep k tile already in LDS: 2 k16 steps x (2x2 tiles) x NP-dependent products
@@ -221,14 +347,14 @@ __device__ __forceinline__ void x3_mma_tile(const unsigned char* As, const unsig
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 a[2][3], b[2][3];
+    u32x4 a[2][3], b[2][3];
     const int co = xswz(l31, 2 * ks + h);   // (row >> 2) & 3 only depends on row mod 16 = l31 mod 16
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
-        a[i][s] = *reinterpret_cast<const bf16x8*>(As + s * XPLANE + (wy * 64 + i * 32 + l31) * XROW + co);
-        b[i][s] = *reinterpret_cast<const bf16x8*>(Bs + s * XPLANE + (wx * 64 + i * 32 + l31) * XROW + co);
+        a[i][s] = *reinterpret_cast<const u32x4*>(As + s * XPLANE + (wy * 64 + i * 32 + l31) * XROW + co);
+        b[i][s] = *reinterpret_cast<const u32x4*>(Bs + s * XPLANE + (wx * 64 + i * 32 + l31) * XROW + co);
       }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -241,7 +367,7 @@ template <bool SYM, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restrict__ T3, int ntk,
                                                              const float* __restrict__ r, float* __restrict__ D, int n,
                                                              int row0, int n_local, long ldD, int tiles_m, int tiles_n,
-                                                             u64* __restrict__ hist0) {
+                                                             u64* __restrict__ hist0, const float* __restrict__ two_s) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XOPER];
   unsigned char* As = smem;
   unsigned char* Bs = smem + XOPER;
@@ -277,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
     x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
     __syncthreads();
   }
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0);
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, *two_s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,7 +412,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
 //   fell into lockstep phases; a producer/consumer split that staged P AND the V tiles through LDS was bound by its
 //   producers (64 KB of loads per k tile accepted at the vector-L1 rate while they also ran the exp/split VALU work).
 //   Here a 768-thread workgroup owns a 128 x 256 tile of [K.G | K.theta]:
-//     waves 0-3   PRODUCERS  load the D tile, P = exp2(c D), split into bf16 planes, fill LDS stage (it+1) & 1
+//     waves 0-3   PRODUCERS  load the D tile, P = exp2(c D), split into 16-bit planes, fill LDS stage (it+1) & 1
 //     waves 4-11  CONSUMERS  each owns all 128 rows x 32 columns: A fragments (P) by ds_read from LDS stage it & 1,
 //                            B fragments (V) by one coalesced 1 KB global load each, issued one k tile ahead right
 //                            after the registers' last use; 48 MFMAs per k tile and wave
@@ -305,7 +431,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
                                                          long ntj, const float* __restrict__ h2p,
                                                          float* __restrict__ OG, float* __restrict__ OT,
                                                          float* __restrict__ RS, int n, int d, int n_local,
-                                                         int tiles_m, int cblocks, int split, int jchunk) {
+                                                         int tiles_m, int cblocks, int split, int jchunk,
+                                                         const float* __restrict__ sc, int dc) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FS_STAGE];
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -330,6 +457,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     float4 rdX[4], rdY[4];
     u32 doff[4];
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
+    constexpr float pofs = (float)SplitTraits<NP>::pexp;        // P carries 2^pexp (undone by the out-scales)
     // the D tile (tile_m, j0 / 32) is one contiguous [128][32] block of the tile-major distance image (rows past
     // n_local exist as padding and only feed accumulator rows that are never stored)
 #pragma unroll
@@ -346,10 +474,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         float4 q4;
-        q4.x = __builtin_amdgcn_exp2f(cexp * rd[p].x);
-        q4.y = __builtin_amdgcn_exp2f(cexp * rd[p].y);
-        q4.z = __builtin_amdgcn_exp2f(cexp * rd[p].z);
-        q4.w = __builtin_amdgcn_exp2f(cexp * rd[p].w);
+        q4.x = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].x, pofs));
+        q4.y = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].y, pofs));
+        q4.z = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].z, pofs));
+        q4.w = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].w, pofs));
         if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
           const int j = j0 + lc;
           q4.x = (j + 0 < jend) ? q4.x : 0.f;
@@ -358,14 +486,13 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
           q4.w = (j + 3 < jend) ? q4.w : 0.f;
         }
         unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
-        if (NP == 3) {
+        if (NP >= 2) {
           rs[p] += (q4.x + q4.y) + (q4.z + q4.w);
-          u32 h0, m0, l0, h1, m1, l1;
-          split3_pair(q4.x, q4.y, h0, m0, l0);
-          split3_pair(q4.z, q4.w, h1, m1, l1);
-          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(m0, m1);
-          *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = make_uint2(l0, l1);
+          u32 wa[3], wb[3];
+          split_pair<NP>(q4.x, q4.y, wa);
+          split_pair<NP>(q4.z, q4.w, wb);
+#pragma unroll
+          for (int s = 0; s < NP; ++s) *reinterpret_cast<uint2*>(dst + s * XPLANE) = make_uint2(wa[s], wb[s]);
         } else {
           // bf16 operands: K is rounded to bf16 once and BOTH uses of it (K.theta in the MFMA and rowsum(K) here) see
           // the rounded value, so the repulsion term sum_j K_ij (theta_i - theta_j) stays consistent
@@ -421,7 +548,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
         sum += __shfl_xor(sum, 2);
         sum += __shfl_xor(sum, 4);
         const int row = i0 + lr + 32 * p;
-        if ((pt & 7) == 0 && row < n_local) RS[(size_t)z * n_local + row] = sum;
+        if ((pt & 7) == 0 && row < n_local) RS[(size_t)z * n_local + row] = sum * sc[4 * dc + 2];
       }
     }
   } else {
@@ -453,17 +580,12 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     };
     // A fragments are read one 16-row block ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
     // all 24 reads (96 registers) to the top of the tile
-    auto read_a = [&](const unsigned char* As, int i, bf16x8 (&a)[3]) {
+    auto read_a = [&](const unsigned char* As, int i, u32x4 (&a)[3]) {
 #pragma unroll
-      for (int s = 0; s < NP; ++s) a[s] = *reinterpret_cast<const bf16x8*>(As + aoff + i * 16 * XROW + s * XPLANE);
+      for (int s = 0; s < NP; ++s) a[s] = *reinterpret_cast<const u32x4*>(As + aoff + i * 16 * XROW + s * XPLANE);
     };
-    auto mma_tile = [&](const unsigned char* As, const u32x4 (&braw)[2][3]) {
-      bf16x8 b[2][3];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int s = 0; s < NP; ++s) b[j][s] = __builtin_bit_cast(bf16x8, braw[j][s]);
-      bf16x8 a[2][3];
+    auto mma_tile = [&](const unsigned char* As, const u32x4 (&b)[2][3]) {
+      u32x4 a[2][3];
       read_a(As, 0, a[0]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -512,16 +634,18 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #endif
     float* __restrict__ Oz = (g < cblocks ? OG : OT) + (size_t)z * n_local * d;
     const int cbase = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + l15;
+    const float* __restrict__ osc = sc + (g < cblocks ? 2 : 3) * dc;   // out-scales of this wave's matrix
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = cbase + j * 16;
       if (col >= d) continue;
+      const float os = osc[col];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = i0 + i * 16 + 4 * lq + e;
-          if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e];
+          if (row < n_local) Oz[(size_t)row * d + col] = acc[i][j][e] * os;
         }
     }
   }
@@ -530,37 +654,64 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 // ================================================================================================
 // host side
 // ================================================================================================
+// split KIND of a call: bf16 inputs -> 1; fp32 inputs -> 2 (two fp16 terms), or 3 (three bf16 terms) when the
+// environment says STEIN_SPLIT_KIND=b3 (kept for accuracy / speed comparisons; read once per process)
+static int split_kind(int dtype) {
+  static const int f32_kind = [] {
+    const char* e = getenv("STEIN_SPLIT_KIND");
+    return (e && e[0] == 'b' && e[1] == '3') ? 3 : 2;
+  }();
+  return dtype == STEIN_BF16 ? 1 : f32_kind;
+}
+int stein_x3_kind(int dtype) { return split_kind(dtype); }
+
+template <typename TIN, int KIND>
+static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score, int64_t n, int64_t d,
+                         const SteinLayout& L, u16* T3, u16* Tt3, u16* Gt3, const float* sc) {
+  const int64_t rows = L.x3_rows > L.x3_nk ? L.x3_rows : L.x3_nk;   // particle extent to cover (both multiples of 32)
+  const int64_t cols = L.x3_dk > L.x3_dc ? L.x3_dk : L.x3_dc;      // parameter extent
+  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+  const dim3 grid_g((unsigned)((L.x3_dc + 63) / 64), (unsigned)((L.x3_nk + 63) / 64));
+  const int dc = (int)L.x3_dc;
+  hipLaunchKernelGGL((k_split<TIN, KIND>), grid, dim3(256), 0, stream, theta, (int)n, (int)d, T3, (long)L.x3_rows,
+                     (int)L.x3_dk, Tt3, dc, (long)L.x3_nk, sc + 4 * dc, sc + dc);
+  hipLaunchKernelGGL((k_split<TIN, KIND>), grid_g, dim3(256), 0, stream, score, (int)n, (int)d, (u16*)nullptr, 0l, 32,
+                     Gt3, dc, (long)L.x3_nk, (const float*)nullptr, sc);
+}
+
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
                    const SteinLayout& L, char* planes, hipStream_t stream) {
   u16* T3 = reinterpret_cast<u16*>(planes + L.x3_t3);
   u16* Tt3 = reinterpret_cast<u16*>(planes + L.x3_tt3);
   u16* Gt3 = reinterpret_cast<u16*>(planes + L.x3_gt3);
-  const int64_t rows = L.x3_rows > L.x3_nk ? L.x3_rows : L.x3_nk;   // particle extent to cover (both multiples of 32)
-  const int64_t cols = L.x3_dk > L.x3_dc ? L.x3_dk : L.x3_dc;      // parameter extent
-  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-  const dim3 grid_g((unsigned)((L.x3_dc + 63) / 64), (unsigned)((L.x3_nk + 63) / 64));
-  if (dtype == STEIN_BF16) {
-    hipLaunchKernelGGL(k_split3<u16>, grid, dim3(256), 0, stream, (const u16*)theta_all, (int)n, (int)d, T3,
-                       (long)L.x3_rows, (int)L.x3_dk, Tt3, (int)L.x3_dc, (long)L.x3_nk);
-    LAUNCH_CHECK("k_split3(theta)");
-    hipLaunchKernelGGL(k_split3<u16>, grid_g, dim3(256), 0, stream, (const u16*)score_all, (int)n, (int)d,
-                       (u16*)nullptr, 0l, 32, Gt3, (int)L.x3_dc, (long)L.x3_nk);
-  } else {
-    hipLaunchKernelGGL(k_split3<float>, grid, dim3(256), 0, stream, (const float*)theta_all, (int)n, (int)d, T3,
-                       (long)L.x3_rows, (int)L.x3_dk, Tt3, (int)L.x3_dc, (long)L.x3_nk);
-    LAUNCH_CHECK("k_split3(theta)");
-    hipLaunchKernelGGL(k_split3<float>, grid_g, dim3(256), 0, stream, (const float*)score_all, (int)n, (int)d,
-                       (u16*)nullptr, 0l, 32, Gt3, (int)L.x3_dc, (long)L.x3_nk);
+  float* sc = reinterpret_cast<float*>(planes + L.x3_sc);
+  const int dc = (int)L.x3_dc;
+  u32* cmax = reinterpret_cast<u32*>(sc + 4 * dc + 4);
+  const int kind = split_kind(dtype);
+  if (kind == 2) {
+    HIP_TRY(hipMemsetAsync(cmax, 0, (size_t)2 * dc * sizeof(u32), stream));
+    int gy = (int)((n + 63) / 64);
+    if (gy > 256) gy = 256;
+    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy);
+    hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (int)n, (int)d, cmax);
+    hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)theta_all, (int)n, (int)d, cmax + dc);
+    LAUNCH_CHECK("k_colmax");
   }
-  LAUNCH_CHECK("k_split3(score)");
+  hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(256), 0, stream, cmax, dc, sc, kind == 2 ? PEXP_H2 : 0,
+                     kind == 2 ? 1 : 0);
+  LAUNCH_CHECK("k_make_scales");
+  if (kind == 1) launch_split<u16, 1>(stream, (const u16*)theta_all, (const u16*)score_all, n, d, L, T3, Tt3, Gt3, sc);
+  else if (kind == 2) launch_split<float, 2>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
+  else launch_split<float, 3>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
+  LAUNCH_CHECK("k_split");
   return STEIN_OK;
 }
 
 template <bool SYM, int NP>
 static void launch_distance_x3(long nblk, hipStream_t stream, const u16* T3, int ntk, const float* r, float* D, int n,
-                               int row0, int n_local, long ld, int tiles_m, int tiles_n, u64* hist0) {
+                               int row0, int n_local, long ld, int tiles_m, int tiles_n, u64* hist0, const float* two_s) {
   hipLaunchKernelGGL((k_distance_x3<SYM, NP>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r, D, n, row0,
-                     n_local, ld, tiles_m, tiles_n, hist0);
+                     n_local, ld, tiles_m, tiles_n, hist0, two_s);
 }
 
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
@@ -568,15 +719,18 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
                       hipStream_t stream) {
   (void)d;
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
+  const float* two_s = reinterpret_cast<const float*>(planes + L.x3_sc) + 4 * L.x3_dc + 1;
   const int ntk = (int)(L.x3_dk / 32);
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
   if (row0 + (int64_t)tiles_m * BM > L.x3_rows) return stein_fail(STEIN_E_SHAPE, "row block exceeds the padded planes");
   const long nblk = symmetric ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
-  const bool one = dtype == STEIN_BF16;
-  if (symmetric && one) launch_distance_x3<true, 1>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
-  else if (symmetric) launch_distance_x3<true, 3>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
-  else if (one) launch_distance_x3<false, 1>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
-  else launch_distance_x3<false, 3>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0);
+#define X3_DIST(SYM, NP) launch_distance_x3<SYM, NP>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0, two_s)
+  switch (split_kind(dtype)) {
+    case 1: if (symmetric) X3_DIST(true, 1); else X3_DIST(false, 1); break;
+    case 2: if (symmetric) X3_DIST(true, 2); else X3_DIST(false, 2); break;
+    default: if (symmetric) X3_DIST(true, 3); else X3_DIST(false, 3); break;
+  }
+#undef X3_DIST
   LAUNCH_CHECK("k_distance_x3");
   return STEIN_OK;
 }
@@ -586,15 +740,15 @@ int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* pl
                               int64_t n_local, hipStream_t stream) {
   const u16* Tt3 = reinterpret_cast<const u16*>(planes + L.x3_tt3);
   const u16* Gt3 = reinterpret_cast<const u16*>(planes + L.x3_gt3);
+  const float* sc = reinterpret_cast<const float*>(planes + L.x3_sc);
   const long nblk = (long)L.tiles_m * L.cblocks * L.split;
-  if (dtype == STEIN_BF16)
-    hipLaunchKernelGGL(k_phi_x3fs<1>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
-                       (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
-                       (int)L.cblocks, (int)L.split, (int)L.jchunk);
-  else
-    hipLaunchKernelGGL(k_phi_x3fs<3>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3,
-                       (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m,
-                       (int)L.cblocks, (int)L.split, (int)L.jchunk);
+#define X3_PHI(NP) hipLaunchKernelGGL(k_phi_x3fs<NP>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3, (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m, (int)L.cblocks, (int)L.split, (int)L.jchunk, sc, (int)L.x3_dc)
+  switch (split_kind(dtype)) {
+    case 1: X3_PHI(1); break;
+    case 2: X3_PHI(2); break;
+    default: X3_PHI(3); break;
+  }
+#undef X3_PHI
   LAUNCH_CHECK("k_phi_x3fs");
   return STEIN_OK;
 }

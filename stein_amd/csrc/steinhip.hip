@@ -596,7 +596,9 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   L->x3_t3 = 0;
   L->x3_tt3 = t3;
   L->x3_gt3 = t3 + tt3;
-  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 : 0);
+  L->x3_sc = t3 + 2 * tt3;   // scales area: float[4 dc + 4] + u32[2 dc]
+  const size_t scb = align_up((size_t)(6 * L->x3_dc + 4) * 4, 256);
+  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 + scb : 0);
   L->total = at;
   return STEIN_OK;
 }

@@ -1,5 +1,6 @@
-"""GPU: the split-bf16 ("x3") variant of the two GEMMs -- three bf16 terms per fp32 operand, six bf16-MFMA products
-per pair -- must stay inside the same 1e-5 budget as the fp32-MFMA path and agree with it closely."""
+"""GPU: the split-precision ("x3") variant of the two GEMMs -- every fp32 operand as two fp16 terms of its
+power-of-two-scaled value (three products per pair; STEIN_SPLIT_KIND=b3: three bf16 terms, six products) on the 16-bit
+matrix cores -- must stay inside the same 1e-5 budget as the fp32-MFMA path and agree with it closely."""
 import numpy as np
 import pytest
 import torch
@@ -18,8 +19,15 @@ def _inputs(n, d, seed=0):
     return rng.normal(size=(n, d)), rng.normal(size=(n, d))
 
 
+def _split_kind():
+    import os
+    return 3 if os.environ.get("STEIN_SPLIT_KIND", "").startswith("b3") else 2
+
+
 def test_split_planes_reconstruct_fp32(cuda):
-    """hi + mid + lo reproduces every fp32 input to <= 2^-24 relative, in both plane layouts."""
+    """The stored terms (two fp16 terms of the power-of-two-scaled value, or three bf16 terms) reproduce every fp32
+    input: to 2^-22 relative (2^-24 for bf16 x 3) plus, for entries far below their column's maximum, 2^-24 of the
+    scaled unit.  Both plane layouts; padding is zero."""
     n, d = 300, 70
     T64, G64 = _inputs(n, d, 1)
     T64[0, 0], T64[1, 1], T64[2, 2] = 0.0, 1e-30, -3.0e20
@@ -28,16 +36,17 @@ def test_split_planes_reconstruct_fp32(cuda):
     eng = SvgdEngine(n, d, device=cuda, x3=True)
     eng.stages.x3_prepare(T, G, n, d, eng.planes)
     torch.cuda.synchronize()
+    kind = _split_kind()
     rows, dk = (n + 127) // 128 * 128 + 128, (d + 31) // 32 * 32
     dc, nk = (d + 127) // 128 * 128, (n + 31) // 32 * 32
-    raw = eng.planes.view(torch.bfloat16)
+    raw = eng.planes.view(torch.float16 if kind == 2 else torch.bfloat16)
 
     def untile(flat, nrows, nks, fragment_order):
-        """tile-major image [row blocks][k tiles][3 planes][one 128 x 32 plane] -> summed fp32 matrix [nrows, nks]"""
+        """tile-major image [row blocks][k tiles][3 plane slots][one 128 x 32 plane] -> summed fp32 matrix [nrows, nks]"""
         if fragment_order:   # plane stored as [row / 16][chunk][row % 16][8] (stein_x3.hip: vfrag_offset)
-            x = flat.view(nrows // 128, nks // 32, 3, 8, 4, 16, 8).float().sum(2)          # [rb, kt, q, chunk, c, e]
-            return x.permute(0, 2, 4, 1, 3, 5).reshape(nrows, nks)                         # rows (rb,q,c), k (kt,chunk,e)
-        x = flat.view(nrows // 128, nks // 32, 3, 128, 32).float().sum(2)
+            x = flat.view(nrows // 128, nks // 32, 3, 8, 4, 16, 8)[:, :, :kind].double().sum(2)   # [rb, kt, q, chunk, c, e]
+            return x.permute(0, 2, 4, 1, 3, 5).reshape(nrows, nks)                             # rows (rb,q,c), k (kt,chunk,e)
+        x = flat.view(nrows // 128, nks // 32, 3, 128, 32)[:, :, :kind].double().sum(2)
         return x.permute(0, 2, 1, 3).reshape(nrows, nks)
 
     t3 = untile(raw[:3 * rows * dk], rows, dk, False)
@@ -45,11 +54,23 @@ def test_split_planes_reconstruct_fp32(cuda):
     tt3 = untile(raw[off:off + 3 * dc * nk], dc, nk, True)
     off2 = off + (3 * dc * nk * 2 + 255) // 256 * 256 // 2
     gt3 = untile(raw[off2:off2 + 3 * dc * nk], dc, nk, True)
-    tol = 2.0 ** -23
-    assert ((t3[:n, :d] - T).abs() <= tol * T.abs()).all()
+    off_sc = (off2 + (3 * dc * nk * 2 + 255) // 256 * 256 // 2) * 2          # byte offset of the scales area
+    sc = eng.planes[off_sc:off_sc + (4 * dc + 4) * 4].view(torch.float32).double()
+    in_g, in_t, out_g, out_t, s_all, two_s, p_un = sc[:dc], sc[dc:2 * dc], sc[2 * dc:3 * dc], sc[3 * dc:4 * dc], \
+        sc[4 * dc], sc[4 * dc + 1], sc[4 * dc + 2]
+    pexp = 14 if kind == 2 else 0
+    assert torch.equal(in_g * out_g, torch.full_like(in_g, 2.0 ** -pexp)) and p_un == 2.0 ** -pexp
+    assert torch.equal(in_t * out_t, torch.full_like(in_t, 2.0 ** -pexp)) and two_s * s_all * s_all == 2.0
+    Td, Gd = T.double(), G.double()
+    if kind == 2:   # scaled column maxima sit in [2^13, 2^14); the 3e20 outlier makes column 2's other entries "far below"
+        assert ((Td.abs().max(0).values * in_t[:d] >= 2.0 ** 13) & (Td.abs().max(0).values * in_t[:d] < 2.0 ** 14)).all()
+        assert ((Gd.abs().max(0).values * in_g[:d] >= 2.0 ** 13) & (Gd.abs().max(0).values * in_g[:d] < 2.0 ** 14)).all()
+        assert 2.0 ** 13 <= Td.abs().max() * s_all < 2.0 ** 14
+    rel, floor = (2.0 ** -22, 2.0 ** -24) if kind == 2 else (2.0 ** -23, 0.0)
+    assert ((t3[:n, :d] / s_all - Td).abs() <= rel * Td.abs() + floor / s_all).all()
     assert (t3[n:].abs().max() == 0) and (t3[:, d:].abs().max() == 0)          # zero padding
-    assert ((tt3[:d, :n].T - T).abs() <= tol * T.abs()).all()
-    assert ((gt3[:d, :n].T - G).abs() <= tol * G.abs()).all()
+    assert ((tt3[:d, :n].T / in_t[:d] - Td).abs() <= rel * Td.abs() + floor / in_t[:d]).all()
+    assert ((gt3[:d, :n].T / in_g[:d] - Gd).abs() <= rel * Gd.abs() + floor / in_g[:d]).all()
     assert tt3[d:].abs().max() == 0 and tt3[:, n:].abs().max() == 0
 
 
