@@ -75,6 +75,7 @@ class StageClock:
 
 
 def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmup, clock_stages=True):
+    from stein_amd import _lib
     from stein_amd.engine import SvgdEngine
     from stein_amd.optimizers import AdagradGradientDescent
     n, d = wl["n"], wl["d"]
@@ -85,8 +86,26 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
     gd = AdagradGradientDescent(learning_rate=1e-3, alpha=0.9)
     clock = StageClock(torch)
 
+    # Single rank: the fused C call (what SteinSampler.update_particles runs), with the library recording HIP events
+    # at its stage boundaries on the launching stream (STEIN_FLAG_TIMING).  Several ranks: the staged calls with a
+    # HIP event at every mark.
+    fused = world == 1
+    apply_events = []
+    if fused and clock_stages:
+        _lib.timing_reserve(steps)
+
     def step(timed):
-        if timed and clock_stages:
+        if fused:
+            phi = eng.compute_phi(theta, G, timing=timed and clock_stages)
+            if timed and clock_stages:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gd.apply_(theta, phi, eng.sqnorm)
+                e1.record()
+                apply_events.append((e0, e1))
+            else:
+                gd.apply_(theta, phi, eng.sqnorm)
+        elif timed and clock_stages:
             clock.begin_step()
             phi = eng.compute_phi(theta, G, mark=clock.mark)
             gd.apply_(theta, phi, eng.sqnorm)
@@ -112,9 +131,14 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(te.item())
-    stages = clock.summary() if clock_stages else {}
-    if "end" in stages:            # interval end -> apply_end is the optimizer apply kernel
-        stages["apply"] = stages.pop("end")
+    if fused and clock_stages:
+        per_call = _lib.timing_read(steps)
+        stages = {k: round(sum(c[k] for c in per_call) / max(1, len(per_call)), 4) for k in _lib.T_STAGES}
+        stages["apply"] = round(sum(a.elapsed_time(b) for a, b in apply_events) / max(1, len(apply_events)), 4)
+    else:
+        stages = clock.summary() if clock_stages else {}
+        if "end" in stages:            # interval end -> apply_end is the optimizer apply kernel
+            stages["apply"] = stages.pop("end")
     finite = bool(torch.isfinite(theta).all().item())
     return dict(n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
                 ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3)

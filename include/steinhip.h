@@ -45,9 +45,11 @@ enum { STEIN_F32 = 0, STEIN_BF16 = 1, STEIN_F64 = 2 };
 /* flags for stein_svgd_phi / stein_workspace_bytes */
 enum {
   STEIN_FLAG_NONE = 0,
-  STEIN_FLAG_X3 = 1 /* run both GEMMs on the bf16 matrix cores with every fp32 operand split into three bf16 terms
-                       (hi + mid + lo, six products per pair: fp32-level accuracy at ~2.7x the fp32-MFMA rate).
-                       Adds the PLANES section to the workspace. */
+  STEIN_FLAG_X3 = 1, /* run both GEMMs on the 16-bit matrix cores at fp32-level accuracy: every fp32 operand is scaled
+                        by a power of two and split into two fp16 terms, three products per pair (environment
+                        STEIN_SPLIT_KIND=b3: three bf16 terms, six products); see stein_amd/csrc/stein_x3.hip.
+                        bf16 inputs use one bf16 product.  Adds the PLANES section to the workspace. */
+  STEIN_FLAG_TIMING = 4 /* stein_svgd_phi only: record a HIP event at every stage boundary (see stein_timing_reserve) */
 };
 /* flags for the staged distance / histogram calls */
 enum {
@@ -61,13 +63,15 @@ enum {
   STEIN_WS_ROWNORM = 0,  /* float  [n]                      r_i = |theta_i|^2                     */
   STEIN_WS_DIST = 1,     /* float  [n_local][ld_dist]       squared distances, row block          */
   STEIN_WS_HIST = 2,     /* int64  [3 levels][2][2048]      radix-select histograms               */
-  STEIN_WS_SELECT = 3,   /* 64 B   select state (ranks, prefixes, median, h2)                     */
+  STEIN_WS_SELECT = 3,   /* 128 B  select state (ranks, prefixes, median, h2) + the speculative-window state,
+                            which must persist from one stein_svgd_phi call to the next              */
   STEIN_WS_PART_G = 4,   /* float  [split][n_local][d]      partial K.G                           */
   STEIN_WS_PART_T = 5,   /* float  [split][n_local][d]      partial K.theta                       */
   STEIN_WS_PART_RS = 6,  /* float  [split][n_local]         partial rowsum(K)                     */
   STEIN_WS_SQPART = 7,   /* double [sq_blocks]              per-block partial |phi|^2             */
-  STEIN_WS_PLANES = 8,   /* split-bf16 operand planes (STEIN_FLAG_X3 only; empty otherwise), always last  */
-  STEIN_WS_NSECTIONS = 9
+  STEIN_WS_SPEC = 8,     /* 16 MB  entries caught by the speculative median window (stein_svgd_phi only)  */
+  STEIN_WS_PLANES = 9,   /* split-bf16 operand planes (STEIN_FLAG_X3 only; empty otherwise), always last  */
+  STEIN_WS_NSECTIONS = 10
 };
 /* extra[] entries reported by stein_workspace_layout */
 enum { STEIN_WSX_LD_DIST = 0, STEIN_WSX_SPLIT = 1, STEIN_WSX_SQ_BLOCKS = 2, STEIN_WSX_HIST_BINS = 3, STEIN_WSX_N = 4 };
@@ -166,6 +170,22 @@ int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t r
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
                           void* workspace, size_t ws_bytes, int flags /* same STEIN_FLAG_* as the partial */,
                           void* stream);
+
+/* Stage timing of the fused call (profiling aid; process-global, not thread-safe).  stein_timing_reserve(calls)
+ * creates the HIP events for `calls` fused calls and rewinds the cursor; each stein_svgd_phi call made with
+ * STEIN_FLAG_TIMING then records an event at every stage boundary on its stream while reserved slots last.
+ * stein_timing_read waits for the recorded events and returns the stage durations in milliseconds,
+ * ms_out[call * STEIN_T_NSTAGES + stage]; *calls_out = calls reported (<= max_calls). */
+enum {
+  STEIN_T_PREPARE = 0,  /* row norms, operand scales and planes, median set-up */
+  STEIN_T_DISTANCE = 1, /* distance pass (+ level-0 histogram, speculative window) */
+  STEIN_T_MEDIAN = 2,   /* window selection or radix-select passes */
+  STEIN_T_CONTRACT = 3, /* K.[G|theta] partial contraction */
+  STEIN_T_FINISH = 4,   /* phi, |phi|^2 */
+  STEIN_T_NSTAGES = 5
+};
+int stein_timing_reserve(int calls);
+int stein_timing_read(float* ms_out, int max_calls, int* calls_out);
 
 /* ---- optimizer apply ---------------------------------------------------------------------------
  * Fuses the norm clip  phi *= 10 / max(10, |phi|_F)  (abstract_stein_sampler.py:125), the optimizer

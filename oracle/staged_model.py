@@ -142,5 +142,5 @@ class NumpyStages:
     def kernel_matrix(self, D, ld, n_local, n, h2, K):
         K.numpy()[:] = np.exp(-D.numpy()[:n_local, :n] / h2.numpy()[0] / np.float32(2))
 
-    def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws):
+    def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws, flags=0):
         raise RuntimeError("the model backend only implements the staged calls")

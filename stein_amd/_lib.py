@@ -13,13 +13,15 @@ LIB_PATH = os.path.join(_HERE, "libsteinhip.so")
 OK, E_BADARG, E_SHAPE, E_WORKSPACE, E_HIP, E_RCCL, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 F32, BF16, F64 = 0, 1, 2
 
-WS_ROWNORM, WS_DIST, WS_HIST, WS_SELECT, WS_PART_G, WS_PART_T, WS_PART_RS, WS_SQPART, WS_PLANES = range(9)
-WS_NSECTIONS = 9
+WS_ROWNORM, WS_DIST, WS_HIST, WS_SELECT, WS_PART_G, WS_PART_T, WS_PART_RS, WS_SQPART, WS_SPEC, WS_PLANES = range(10)
+WS_NSECTIONS = 10
 WSX_LD_DIST, WSX_SPLIT, WSX_SQ_BLOCKS, WSX_HIST_BINS = range(4)
 WSX_N = 4
 HIST_BINS, HIST_LEVELS = 2048, 3
 STAGE_SYMMETRIC = 1
 FLAG_X3 = 1
+FLAG_TIMING = 4
+T_STAGES = ("prepare", "distance", "median", "contract", "finish")   # STEIN_T_* of include/steinhip.h
 
 _c = ctypes
 _vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.c_size_t
@@ -28,6 +30,8 @@ _vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.
 _SIGNATURES = {
     "stein_workspace_bytes": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz)],
     "stein_workspace_layout": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz), _c.POINTER(_i64)],
+    "stein_timing_reserve": [_int],
+    "stein_timing_read": [_c.POINTER(_c.c_float), _int, _c.POINTER(_int)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_rownorms": [_vp, _i64, _i64, _int, _vp, _vp],
     "stein_distance_block": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _int, _vp],
@@ -98,3 +102,17 @@ def workspace_layout(n_local, n, d, dtype=F32, flags=0):
 
 def version():
     return load().stein_version()
+
+
+def timing_reserve(calls):
+    """Reserve HIP events for `calls` fused calls made with FLAG_TIMING (and rewind the cursor)."""
+    call("stein_timing_reserve", int(calls))
+
+
+def timing_read(max_calls):
+    """-> list of {stage: ms} for the timed fused calls since timing_reserve (waits for their events)."""
+    buf = (_c.c_float * (max_calls * len(T_STAGES)))()
+    got = _int(0)
+    call("stein_timing_read", buf, int(max_calls), _c.byref(got))
+    k = len(T_STAGES)
+    return [{T_STAGES[j]: float(buf[i * k + j]) for j in range(k)} for i in range(got.value)]

@@ -94,6 +94,36 @@ struct SelState {
 };
 static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
 
+// Speculative median window (single-rank fused call only).  SVGD moves the particles a little per step, so the
+// median of the n^2 distances drifts smoothly.  The distance epilogue counts the entries below a narrow key window
+// around the median extrapolated from the two previous steps and appends the entries inside it to a buffer; if both median targets
+// turn out to lie inside the window, an exact weighted selection over that buffer (k_spec_select) replaces the two
+// radix-select passes over D.  Otherwise (first step, jump, overflow) the passes run as before: exact either way.
+// Lives right after SelState in the SELECT section and persists across steps (garbage until `magic` is set).
+struct SpecState {
+  u32 magic;      // SPEC_MAGIC1 once one median has been recorded, SPEC_MAGIC2 once two have (velocity known)
+  u32 center;     // predicted key of this step's lower median target: last + (last - the one before), linear
+                  // extrapolation in key space (the median drifts almost linearly from step to step)
+  u32 halfwidth;  // half-width of the next window, in key units: follows the last prediction error
+  u32 lo_key;     // this step's window [lo_key, lo_key + width]; lo_key = 0xffffffff, width = 0: no window
+  u32 width;
+  u32 count;      // entries appended this step (may exceed the buffer capacity -> overflow -> miss)
+  u32 overflow;   // a workgroup's LDS queue overflowed
+  u32 hit;        // this step's median came from the window; the radix-select passes skip themselves
+  u64 below;      // (unused: the weight below the window is summed from the slots at the head of the buffer)
+  u64 total;      // n * n
+  u32 last_key;   // key of the previous step's lower median target
+  u32 pad32;
+  u64 pad;
+};
+static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
+constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;
+constexpr u32 SPEC_QCAP = 1984;          // per-workgroup LDS queue (entries of 8 bytes)
+constexpr u32 SPEC_CAP = (1u << 21) - 2048u;   // global buffer capacity (entries); the 16 MB section starts with
+constexpr u32 SPEC_SLOTS = 256;                 // 256 "below" counters, one per 64-byte line (8 u64 apart): every
+                                                // workgroup adding to ONE address serialised at the L2 (+165 us)
+constexpr u32 SPEC_HW_MAX = 32767;       // window <= 65535 keys: two 8-bit selection passes
+
 __device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
   const u32 u = __float_as_uint(x);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -136,10 +166,18 @@ __device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane
 //
 // The body is instantiated three times -- interior tile (no predicates), edge tile, diagonal tile -- and the
 // workgroup picks one with a single uniform branch.
-template <bool MIRROR, bool PRED, bool DIAG, bool HIST>
+struct SpecCtx {   // per-thread view of the speculative window (SPEC epilogues only)
+  u32 lo, width;   // window [lo, lo + width] in key space
+  u32* qcnt;       // LDS: entries pushed by this workgroup
+  u64* q;          // LDS queue, SPEC_QCAP entries of (key << 2 | weight)
+  u32 below;       // this thread's weight of entries below the window
+};
+
+template <bool MIRROR, bool PRED, bool DIAG, bool HIST, bool SPEC>
 __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int row0, int n_local, long ldD,
-                                                       int tile_m, int brow0, u32 base, u64& packed, float two_s) {
+                                                       int tile_m, int brow0, u32 base, u64& packed, float two_s,
+                                                       SpecCtx& sx) {
   const long ntc = ldD >> 5;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
@@ -168,10 +206,18 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
             D[d_index(lrow, col, ntc)] = v[q];
             if (DIAG && w == 2u) D[d_index(col, lrow, ntc)] = v[q];
             if (HIST) {
-              const u32 dg = f32_key(v[q]) >> 21;
+              const u32 key = f32_key(v[q]);
+              const u32 dg = key >> 21;
               const u32 off = dg - base;
               if (off < 8u) packed += (u64)w << (8u * off);
               else atomicAdd(&hl[dg], w);
+              if (SPEC) {
+                sx.below += key < sx.lo ? w : 0u;
+                if (key - sx.lo <= sx.width) {   // rare: a fraction of a percent of the entries
+                  const u32 slot = atomicAdd(sx.qcnt, 1u);
+                  if (slot < SPEC_QCAP) sx.q[slot] = ((u64)key << 2) | w;
+                }
+              }
             }
           }
         }
@@ -184,12 +230,14 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
   }
 }
 
-// `hl` is >= 8 KB of LDS that the caller no longer needs (all waves must be past their last LDS read).
+// `hl` is LDS that the caller no longer needs (all waves must be past their last LDS read): 8 KB for the histogram,
+// 8 KB + 64 B + 8 SPEC_QCAP B with a speculative window (spec != NULL, which needs hist0 != NULL).
 template <bool SYM>
 __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                   float* __restrict__ D, int n, int row0, int n_local, long ldD,
                                                   int tile_m, int tile_n, u64* __restrict__ hist0,
-                                                  float two_s = 2.f) {
+                                                  float two_s = 2.f, SpecState* __restrict__ spec = nullptr,
+                                                  u64* __restrict__ spec_buf = nullptr) {
   // two_s: D = r_i + r_j - two_s * acc.  2 for S = T T^T accumulated at full scale; the split kernels accumulate the
   // product of operands pre-scaled by a power of two and pass 2 / scale^2 (exact either way)
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -197,8 +245,17 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   const int brow0 = tile_n * BN;
   u64 packed = 0ull;
   u32 base = 0u;
+  SpecCtx sx;
+  sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u;
+  sx.qcnt = hl + STEIN_HIST_BINS;                               // 16 u32 reserved
+  sx.q = reinterpret_cast<u64*>(hl + STEIN_HIST_BINS + 16);
   if (hist0) {
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
+    if (spec) {
+      if (t == 0) { sx.qcnt[0] = 0u; sx.qcnt[2] = 0u; }
+      sx.lo = spec->lo_key;
+      sx.width = spec->width;
+    }
     __syncthreads();
     const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - two_s * acc[0][0][0];
     base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
@@ -208,10 +265,15 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   const bool edge = brow0 + BN > n || tile_m * BM + BM > n_local;
 #define STEIN_EPI(MIRROR, PRED, DIAG)                                                                                  \
   do {                                                                                                                 \
-    if (hist0) distance_epilogue_body<MIRROR, PRED, DIAG, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,  \
-                                                                base, packed, two_s);                                 \
-    else distance_epilogue_body<MIRROR, PRED, DIAG, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0, base, \
-                                                           packed, two_s);                                            \
+    if (hist0 && spec)                                                                                                 \
+      distance_epilogue_body<MIRROR, PRED, DIAG, true, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,     \
+                                                             base, packed, two_s, sx);                                \
+    else if (hist0)                                                                                                    \
+      distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
+                                                              base, packed, two_s, sx);                               \
+    else                                                                                                               \
+      distance_epilogue_body<MIRROR, PRED, DIAG, false, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,   \
+                                                               base, packed, two_s, sx);                              \
   } while (0)
   if (diag) STEIN_EPI(false, true, true);
   else if (edge) STEIN_EPI(SYM, true, false);
@@ -225,9 +287,33 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
       for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
       if (lane == 0 && c) atomicAdd(&hl[base + k], c);
     }
+    if (spec) {   // weight below the window: wave sum -> LDS -> one global atomic per workgroup, spread over slots
+      u32 b = sx.below;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
+      if (lane == 0 && b) atomicAdd(&sx.qcnt[2], b);
+    }
     __syncthreads();
+    if (spec && t == 0 && sx.qcnt[2])
+      atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + (blockIdx.x % SPEC_SLOTS) * 8),
+                (unsigned long long)sx.qcnt[2]);
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS)
       if (hl[b]) atomicAdd(&hist0[b], (u64)hl[b]);
+    if (spec) {   // flush the workgroup's queue to the global buffer
+      const u32 pushed = *sx.qcnt;
+      const u32 nq = min(pushed, SPEC_QCAP);
+      if (nq) {
+        __syncthreads();
+        if (t == 0) {
+          if (pushed > SPEC_QCAP) spec->overflow = 1u;
+          sx.qcnt[1] = atomicAdd(&spec->count, nq);
+        }
+        __syncthreads();
+        const u32 gbase = sx.qcnt[1];
+        for (u32 i = t; i < nq; i += NTHREADS)
+          if (gbase + i < SPEC_CAP) spec_buf[SPEC_SLOTS * 8 + gbase + i] = sx.q[i];
+      }
+    }
   }
 }
 

@@ -9,7 +9,7 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
                    char* planes, hipStream_t stream);
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                       int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
-                      hipStream_t stream);
+                      hipStream_t stream, SpecState* spec = nullptr, u64* spec_buf = nullptr);
 int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L, int dtype,
                               const float* h2_dev, float* OG, float* OT, float* RS, int64_t n, int64_t d,
                               int64_t n_local, hipStream_t stream);

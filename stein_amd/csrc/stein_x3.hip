@@ -367,7 +367,8 @@ template <bool SYM, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restrict__ T3, int ntk,
                                                              const float* __restrict__ r, float* __restrict__ D, int n,
                                                              int row0, int n_local, long ldD, int tiles_m, int tiles_n,
-                                                             u64* __restrict__ hist0, const float* __restrict__ two_s) {
+                                                             u64* __restrict__ hist0, const float* __restrict__ two_s,
+                                                             SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XOPER];
   unsigned char* As = smem;
   unsigned char* Bs = smem + XOPER;
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
     x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
     __syncthreads();
   }
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, *two_s);
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, *two_s,
+                         spec, spec_buf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -709,14 +711,15 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
 
 template <bool SYM, int NP>
 static void launch_distance_x3(long nblk, hipStream_t stream, const u16* T3, int ntk, const float* r, float* D, int n,
-                               int row0, int n_local, long ld, int tiles_m, int tiles_n, u64* hist0, const float* two_s) {
+                               int row0, int n_local, long ld, int tiles_m, int tiles_n, u64* hist0, const float* two_s,
+                               SpecState* spec, u64* spec_buf) {
   hipLaunchKernelGGL((k_distance_x3<SYM, NP>), dim3((unsigned)nblk), dim3(NTHREADS), 0, stream, T3, ntk, r, D, n, row0,
-                     n_local, ld, tiles_m, tiles_n, hist0, two_s);
+                     n_local, ld, tiles_m, tiles_n, hist0, two_s, spec, spec_buf);
 }
 
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                       int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
-                      hipStream_t stream) {
+                      hipStream_t stream, SpecState* spec, u64* spec_buf) {
   (void)d;
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
   const float* two_s = reinterpret_cast<const float*>(planes + L.x3_sc) + 4 * L.x3_dc + 1;
@@ -724,7 +727,7 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
   if (row0 + (int64_t)tiles_m * BM > L.x3_rows) return stein_fail(STEIN_E_SHAPE, "row block exceeds the padded planes");
   const long nblk = symmetric ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
-#define X3_DIST(SYM, NP) launch_distance_x3<SYM, NP>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0, two_s)
+#define X3_DIST(SYM, NP) launch_distance_x3<SYM, NP>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0, two_s, spec, spec_buf)
   switch (split_kind(dtype)) {
     case 1: if (symmetric) X3_DIST(true, 1); else X3_DIST(false, 1); break;
     case 2: if (symmetric) X3_DIST(true, 2); else X3_DIST(false, 2); break;

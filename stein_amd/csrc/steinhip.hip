@@ -26,6 +26,8 @@
 #include "stein_common.h"
 #include "stein_x3.h"
 
+#include <vector>
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -126,7 +128,8 @@ __global__ void k_sel_init(SelState* st, u64 total) {
 template <bool VEC, bool SYM>
 __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__ T, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int d, int row0, int n_local,
-                                                       long ldD, int tiles_m, int tiles_n, u64* __restrict__ hist0) {
+                                                       long ldD, int tiles_m, int tiles_n, u64* __restrict__ hist0,
+                                                       SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
   float* As = smem;
   float* Bs = smem + BM * LDK;
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__
   }
 
   // the staging tiles are dead (every wave is past the loop's last barrier): 8 KB of them hold the level-0 histogram
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0);
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, 2.f,
+                         spec, spec_buf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,7 +196,9 @@ __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__
 // values inside the selected bin, spread over up to 2048 digits -> plain LDS atomics are cheaper.
 template <int LEVEL, bool SYM>
 __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
-                                              const SelState* __restrict__ st, u64* __restrict__ hist) {
+                                              const SelState* __restrict__ st, u64* __restrict__ hist,
+                                              const u32* __restrict__ skip) {
+  if (skip && *skip) return;   // the speculative window already produced this step's median
   __shared__ u32 h[2 * STEIN_HIST_BINS];
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
   __syncthreads();
@@ -246,7 +252,8 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
 
 // one wave; hist points at this level's [2][STEIN_HIST_BINS] counters (already summed over ranks)
 __global__ __launch_bounds__(64) void k_resolve(const u64* __restrict__ hist, int level, SelState* st, float ln_n,
-                                                float* h2_out, float* median_out) {
+                                                float* h2_out, float* median_out, const u32* __restrict__ skip) {
+  if (skip && *skip) return;
   __shared__ u64 bins[STEIN_HIST_BINS];
   __shared__ u64 chunk[64];
   const int lane = threadIdx.x;
@@ -290,6 +297,134 @@ __global__ __launch_bounds__(64) void k_resolve(const u64* __restrict__ hist, in
       if (median_out) *median_out = med;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// speculative median window (SpecState in stein_common.h): begin / select / update, one launch each per step
+// ------------------------------------------------------------------------------------------------
+// fused-call prologue: k_sel_init + the window set-up + zeroing of the histograms and of the "below" slots
+__global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp, u64 total, u64* __restrict__ hist,
+                                                     u64* __restrict__ slots) {
+  const int gt = blockIdx.x * 256 + threadIdx.x, gn = gridDim.x * 256;
+  for (int i = gt; i < STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS; i += gn) hist[i] = 0ull;
+  for (int i = gt; i < (int)SPEC_SLOTS * 8; i += gn) slots[i] = 0ull;
+  if (gt) return;
+  {
+    const u32 even = (total & 1ull) ? 0u : 1u;
+    st->rank[0] = even ? total / 2 - 1 : total / 2;
+    st->rank[1] = total / 2;
+    st->prefix[0] = st->prefix[1] = 0u;
+    st->diverged = 0u;
+    st->even = even;
+    st->median = st->h2 = st->lo = st->hi = 0.f;
+  }
+  if ((sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) && sp->halfwidth <= SPEC_HW_MAX &&
+      sp->center >= sp->halfwidth && sp->center <= 0xfffffffeu - sp->halfwidth) {
+    sp->lo_key = sp->center - sp->halfwidth;
+    sp->width = 2u * sp->halfwidth;
+  } else {
+    sp->lo_key = 0xffffffffu;   // no window: nothing is inside, everything is "below" (and ignored)
+    sp->width = 0u;
+  }
+  sp->count = 0u; sp->overflow = 0u; sp->hit = 0u;
+  sp->below = 0ull; sp->total = total;
+}
+
+// All 256 bins of an LDS histogram -> the bin holding 0-based rank `rank` and the rank inside it; *bin = 256 when the
+// rank lies past the last bin.  Called by the whole workgroup (>= 256 threads); `scan` is 256 words of LDS scratch.
+__device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u32* bin, u32* rest) {
+  const int t = threadIdx.x;
+  if (t < 256) scan[t] = h[t];
+  if (t == 0) *bin = 256u;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scan
+    u32 v = 0u;
+    if (t < 256 && t >= o) v = scan[t - o];
+    __syncthreads();
+    if (t < 256) scan[t] += v;
+    __syncthreads();
+  }
+  if (t < 256) {
+    const u32 incl = scan[t], excl = incl - h[t];
+    if (excl <= rank && rank < incl) { *bin = (u32)t; *rest = rank - excl; }
+  }
+  __syncthreads();
+}
+
+// One workgroup: exact weighted selection of the two median targets among the buffered window entries.
+// Entry = key << 2 | weight, offset o = key - lo_key < 65536: pass 1 histograms o >> 8, pass 2 the low byte of the
+// entries that share each target's high byte.
+__global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* sp, const u64* __restrict__ slots,
+                                                      float ln_n, float* h2_out) {
+  const u64* __restrict__ buf = slots + SPEC_SLOTS * 8;
+  __shared__ u32 h1[256], h2a[256], h2b[256], scan[256];
+  __shared__ u32 sel[8];   // [0,1] high bytes, [2,3] ranks inside them, [4,5] low bytes, [6,7] scratch
+  __shared__ u64 below_s;
+  const int t = threadIdx.x;
+  const u32 cnt = sp->count, lo = sp->lo_key;
+  if (sp->width == 0u || sp->overflow || cnt > SPEC_CAP || cnt == 0u) return;   // miss: the radix passes run
+  if (t == 0) below_s = 0ull;
+  if (t < 256) { h1[t] = 0u; h2a[t] = 0u; h2b[t] = 0u; }
+  __syncthreads();
+  if (t < (int)SPEC_SLOTS && slots[t * 8])
+    atomicAdd(reinterpret_cast<unsigned long long*>(&below_s), (unsigned long long)slots[t * 8]);
+  __syncthreads();
+  const u64 total = sp->total, below = below_s;
+  const u64 r0 = (total & 1ull) ? total / 2 : total / 2 - 1, r1 = total / 2;
+  if (r0 < below || r1 - below > 0xfffffff0ull) return;   // the target lies below the window
+  for (u32 i = t; i < cnt; i += 1024) {
+    const u64 e = buf[i];
+    atomicAdd(&h1[((u32)(e >> 2) - lo) >> 8], (u32)e & 3u);
+  }
+  __syncthreads();
+  spec_locate(h1, (u32)(r0 - below), scan, &sel[0], &sel[2]);
+  spec_locate(h1, (u32)(r1 - below), scan, &sel[1], &sel[3]);
+  const u32 ba = sel[0], bb = sel[1];
+  if (ba == 256u || bb == 256u) return;   // a target lies above the window
+  for (u32 i = t; i < cnt; i += 1024) {
+    const u64 e = buf[i];
+    const u32 o = (u32)(e >> 2) - lo, w = (u32)e & 3u;
+    if ((o >> 8) == ba) atomicAdd(&h2a[o & 255u], w);
+    if ((o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
+  }
+  __syncthreads();
+  spec_locate(h2a, sel[2], scan, &sel[4], &sel[6]);
+  spec_locate(h2b, sel[3], scan, &sel[5], &sel[7]);
+  if (t == 0) {
+    const float flo = key_f32(lo + ((ba << 8) | sel[4])), fhi = key_f32(lo + ((bb << 8) | sel[5]));
+    const float med = st->even ? 0.5f * (flo + fhi) : flo;
+    const float bw = sqrtf(med / ln_n);      // abstract_kernel.py:40
+    const float h2 = bw * bw;                // squared_exponential_kernel.py:22 squares it again
+    st->lo = flo; st->hi = fhi; st->median = med; st->h2 = h2;
+    if (h2_out) *h2_out = h2;
+    sp->hit = 1u;
+  }
+}
+
+// after the median is final (window or radix passes): predict the next one and size its window
+__global__ void k_spec_update(const SelState* st, SpecState* sp) {
+  if (threadIdx.x || blockIdx.x) return;
+  const u32 key = f32_key(st->lo);
+  const bool had_window = sp->width != 0u;
+  u32 hw = 4096u, next = key;
+  if (sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) {
+    // linear extrapolation of the VALUE (key space bends at every power of two)
+    const float pred = 2.f * st->lo - key_f32(sp->last_key);
+    long c = (long)f32_key(pred == pred ? pred : st->lo);
+    c = c < 65536l ? 65536l : (c > 0xfffe0000l ? 0xfffe0000l : c);
+    next = (u32)c;
+    if (sp->magic == SPEC_MAGIC2 && had_window) {   // the window of this step was centred on a real prediction
+      const u32 err = key > sp->center ? key - sp->center : sp->center - key;
+      hw = err > SPEC_HW_MAX / 4u ? SPEC_HW_MAX : 4u * err + 48u;
+      if (sp->hit && sp->count > SPEC_CAP / 2 && hw > sp->halfwidth / 2u) hw = sp->halfwidth / 2u + 1u;   // keep the buffer small
+    }
+    sp->magic = SPEC_MAGIC2;
+  } else {
+    sp->magic = SPEC_MAGIC1;
+  }
+  sp->last_key = key;
+  sp->center = next;
+  sp->halfwidth = hw > SPEC_HW_MAX ? SPEC_HW_MAX : hw;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,7 +676,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
-  if (flags & ~STEIN_FLAG_X3) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -581,12 +716,13 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   put(STEIN_WS_ROWNORM, (size_t)n * 4);
   put(STEIN_WS_DIST, align_up((size_t)n_local, DT_ROWS) * L->ld_dist * 4);   // tile-major, rows padded to 128
   put(STEIN_WS_HIST, (size_t)STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS * 8);
-  put(STEIN_WS_SELECT, sizeof(SelState));
+  put(STEIN_WS_SELECT, sizeof(SelState) + sizeof(SpecState));
   put(STEIN_WS_PART_G, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_T, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_RS, (size_t)split * n_local * 4);
   put(STEIN_WS_SQPART, (size_t)sqb * 8);
-  // split-bf16 operand planes: always LAST so the offsets above do not depend on the flag
+  put(STEIN_WS_SPEC, ((size_t)SPEC_CAP + SPEC_SLOTS * 8) * 8);
+  // split operand planes: always LAST so the offsets above do not depend on the flag
   L->x3_rows = (int64_t)align_up((size_t)n, 128) + 128;   // a rank's last row tile may start past roundup(n, 128) - 128
   L->x3_dk = (int64_t)align_up((size_t)d, 32);
   L->x3_dc = (int64_t)align_up((size_t)d, 128);
@@ -661,14 +797,15 @@ extern "C" int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int d
 
 template <bool VEC, bool SYM>
 static void launch_distance(long nblk, hipStream_t s, const float* T, const float* r, float* D, int n, int d, int row0,
-                            int n_local, long ld, int tiles_m, int tiles_n, u64* hist0) {
+                            int n_local, long ld, int tiles_m, int tiles_n, u64* hist0, SpecState* spec, u64* spec_buf) {
   hipLaunchKernelGGL((k_distance<VEC, SYM>), dim3((unsigned)nblk), dim3(NTHREADS), 0, s, T, r, D, n, d, row0, n_local,
-                     ld, tiles_m, tiles_n, hist0);
+                     ld, tiles_m, tiles_n, hist0, spec, spec_buf);
 }
 
-extern "C" int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
-                                    int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* hist_level0,
-                                    const void* x3_planes, int flags, void* stream) {
+// spec != NULL (single-rank fused call only, needs hist_level0): also feed the speculative median window
+static int distance_block_impl(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
+                               int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* hist_level0,
+                               const void* x3_planes, int flags, void* stream, SpecState* spec, u64* spec_buf) {
   if ((!theta_all && !x3_planes) || !r_all || !dist_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (n < 1 || d < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
   if (ld_dist < n || (ld_dist & 63)) return fail(STEIN_E_SHAPE, "ld_dist must be >= n and a multiple of 64");
@@ -686,16 +823,24 @@ extern "C" int stein_distance_block(const void* theta_all, const float* r_all, i
     SteinLayout L;
     int rc = stein_make_layout(n_local, n, d, dtype, STEIN_FLAG_X3, &L);
     if (rc) return rc;
-    return stein_x3_distance((const char*)x3_planes, L, dtype, r_all, dist_out, n, d, row0, n_local, ld_dist, h0, sym, s);
+    return stein_x3_distance((const char*)x3_planes, L, dtype, r_all, dist_out, n, d, row0, n_local, ld_dist, h0, sym, s,
+                             spec, spec_buf);
   }
   const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
   const float* T = (const float*)theta_all;
-  if (vec && sym) launch_distance<true, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
-  else if (vec) launch_distance<true, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
-  else if (sym) launch_distance<false, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
-  else launch_distance<false, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0);
+  if (vec && sym) launch_distance<true, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0, spec, spec_buf);
+  else if (vec) launch_distance<true, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0, spec, spec_buf);
+  else if (sym) launch_distance<false, true>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0, spec, spec_buf);
+  else launch_distance<false, false>(nblk, s, T, r_all, dist_out, (int)n, (int)d, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, h0, spec, spec_buf);
   LAUNCH_CHECK("k_distance");
   return STEIN_OK;
+}
+
+extern "C" int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
+                                    int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* hist_level0,
+                                    const void* x3_planes, int flags, void* stream) {
+  return distance_block_impl(theta_all, r_all, n, d, row0, n_local, dtype, dist_out, ld_dist, hist_level0, x3_planes,
+                             flags, stream, nullptr, nullptr);
 }
 
 extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total, void* stream) {
@@ -710,15 +855,15 @@ extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total,
 
 template <int LEVEL>
 static void launch_hist(bool sym, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
-                        const SelState* st, u64* h) {
+                        const SelState* st, u64* h, const u32* skip) {
   if (sym)
-    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h);
+    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
   else
-    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h);
+    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
 }
 
-extern "C" int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
-                                      const void* select_state, void* hist, int flags, void* stream) {
+static int hist_pass_impl(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
+                          const void* select_state, void* hist, int flags, void* stream, const u32* skip) {
   if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
   if (ld_dist < n || (ld_dist & 31) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape (ld_dist must be a multiple of 32)");
@@ -729,24 +874,34 @@ extern "C" int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_
   u64* h = (u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
   const SelState* st = (const SelState*)select_state;
   hipStream_t s = (hipStream_t)stream;
-  if (level == 0) launch_hist<0>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
-  else if (level == 1) launch_hist<1>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
-  else launch_hist<2>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h);
+  if (level == 0) launch_hist<0>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  else if (level == 1) launch_hist<1>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  else launch_hist<2>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
   LAUNCH_CHECK("k_hist");
   return STEIN_OK;
 }
 
-extern "C" int stein_median_resolve(const void* hist, int level, int64_t n, void* select_state, float* h2_out,
-                                    float* median_out, void* stream) {
+extern "C" int stein_median_hist_pass(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
+                                      const void* select_state, void* hist, int flags, void* stream) {
+  return hist_pass_impl(dist, ld_dist, n_local, n, level, select_state, hist, flags, stream, nullptr);
+}
+
+static int resolve_impl(const void* hist, int level, int64_t n, void* select_state, float* h2_out, float* median_out,
+                        void* stream, const u32* skip) {
   if (!hist || !select_state) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
   if (n < 2) return fail(STEIN_E_BADARG, "n = %lld: need n >= 2", (long long)n);
   const u64* h = (const u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
   const float ln_n = (float)log((double)n);  // np.log(n) in fp64, cast to fp32 by the tf.float32 graph
   hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, h, level, (SelState*)select_state, ln_n,
-                     h2_out, median_out);
+                     h2_out, median_out, skip);
   LAUNCH_CHECK("k_resolve");
   return STEIN_OK;
+}
+
+extern "C" int stein_median_resolve(const void* hist, int level, int64_t n, void* select_state, float* h2_out,
+                                    float* median_out, void* stream) {
+  return resolve_impl(hist, level, n, select_state, h2_out, median_out, stream, nullptr);
 }
 
 extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n,
@@ -838,6 +993,37 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
                                ws_bytes, x3_planes ? STEIN_FLAG_X3 : 0, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage timing of the fused call (profiling aid; process-global, not thread-safe)
+// ------------------------------------------------------------------------------------------------
+static std::vector<hipEvent_t> g_tevents;   // (STEIN_T_NSTAGES + 1) events per reserved call
+static int g_tcalls_reserved = 0, g_tcalls_used = 0;
+
+extern "C" int stein_timing_reserve(int calls) {
+  if (calls < 0) return fail(STEIN_E_BADARG, "calls < 0");
+  const size_t need = (size_t)calls * (STEIN_T_NSTAGES + 1);
+  while (g_tevents.size() < need) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    g_tevents.push_back(e);
+  }
+  g_tcalls_reserved = calls;
+  g_tcalls_used = 0;
+  return STEIN_OK;
+}
+
+extern "C" int stein_timing_read(float* ms_out, int max_calls, int* calls_out) {
+  if (!ms_out || !calls_out) return fail(STEIN_E_BADARG, "NULL pointer");
+  const int calls = g_tcalls_used < max_calls ? g_tcalls_used : max_calls;
+  for (int c = 0; c < calls; ++c) {
+    hipEvent_t* ev = &g_tevents[(size_t)c * (STEIN_T_NSTAGES + 1)];
+    HIP_TRY(hipEventSynchronize(ev[STEIN_T_NSTAGES]));
+    for (int k = 0; k < STEIN_T_NSTAGES; ++k) HIP_TRY(hipEventElapsedTime(&ms_out[c * STEIN_T_NSTAGES + k], ev[k], ev[k + 1]));
+  }
+  *calls_out = calls;
+  return STEIN_OK;
+}
+
 extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0,
                               int64_t n_local, int dtype, float* phi_local, float* h2_out, double* sqnorm_out,
                               float* K_out, float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
@@ -860,19 +1046,47 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   // single rank: the block is the whole symmetric matrix -> upper-triangle distance pass with mirrored stores,
   // level-0 histogram taken in its epilogue, levels 1-2 read the upper triangle only
   const int sf = STEIN_STAGE_SYMMETRIC;
+  SpecState* spec = (SpecState*)((char*)sel + sizeof(SelState));
+  u64* spec_buf = (u64*)(ws + L.off[STEIN_WS_SPEC]);
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t* tev = nullptr;   // STEIN_FLAG_TIMING: one event per stage boundary, while reserved slots last
+  if ((flags & STEIN_FLAG_TIMING) && g_tcalls_used < g_tcalls_reserved)
+    tev = &g_tevents[(size_t)(g_tcalls_used++) * (STEIN_T_NSTAGES + 1)];
+#define STEIN_TSTAMP(k) do { if (tev) HIP_TRY(hipEventRecord(tev[k], s)); } while (0)
+  STEIN_TSTAMP(STEIN_T_PREPARE);
   if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
   if (planes && (rc = stein_x3_prepare(theta_all, score_all, n, d, dtype, planes, L.total - L.off[STEIN_WS_PLANES], stream)))
     return rc;
-  if ((rc = stein_median_begin(hist, sel, n * n, stream))) return rc;
-  if ((rc = stein_distance_block(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream)))
+  hipLaunchKernelGGL(k_median_init, dim3(16), dim3(256), 0, s, (SelState*)sel, spec, (u64)(n * n), (u64*)hist, spec_buf);
+  LAUNCH_CHECK("k_median_init");
+  STEIN_TSTAMP(STEIN_T_DISTANCE);
+  if ((rc = distance_block_impl(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream, spec,
+                                spec_buf)))
     return rc;
+  STEIN_TSTAMP(STEIN_T_MEDIAN);
+  // the window either yields the median now (spec->hit) or the radix-select passes below run; each of them
+  // checks the flag on the device, so nothing here waits for the host
+  hipLaunchKernelGGL(k_spec_select, dim3(1), dim3(1024), 0, s, (SelState*)sel, spec, spec_buf,
+                     (float)log((double)n), h2_out);
+  LAUNCH_CHECK("k_spec_select");
   for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv) {
-    if (lv > 0 && (rc = stein_median_hist_pass(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream))) return rc;
-    if ((rc = stein_median_resolve(hist, lv, n, sel, h2_out, nullptr, stream))) return rc;
+    if (lv > 0 && (rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, &spec->hit))) return rc;
+    if ((rc = resolve_impl(hist, lv, n, sel, h2_out, nullptr, stream, &spec->hit))) return rc;
   }
+  hipLaunchKernelGGL(k_spec_update, dim3(1), dim3(64), 0, s, (const SelState*)sel, spec);
+  LAUNCH_CHECK("k_spec_update");
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;
-  return stein_kernel_contract(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, phi_local,
-                               sqnorm_out, dK_out, planes, workspace, ws_bytes, stream);
+  STEIN_TSTAMP(STEIN_T_CONTRACT);
+  if ((rc = stein_contract_partial(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, planes,
+                                   workspace, ws_bytes, stream)))
+    return rc;
+  STEIN_TSTAMP(STEIN_T_FINISH);
+  if ((rc = stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_out, phi_local, sqnorm_out, dK_out, workspace,
+                                  ws_bytes, planes ? STEIN_FLAG_X3 : 0, stream)))
+    return rc;
+  STEIN_TSTAMP(STEIN_T_NSTAGES);
+#undef STEIN_TSTAMP
+  return STEIN_OK;
 }
 
 template <typename S>

@@ -198,15 +198,18 @@ class SvgdEngine:
         return self.ws[o:self.ws_bytes]
 
     # ---------------------------------------------------------------------------------------
-    def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None, mark=None):
+    def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None, mark=None, timing=False):
         """theta_local, score_local: [n_local, d] float32 contiguous device tensors (this rank's rows).
 
         Returns self.phi ([n_local, d] float32, unclipped).  Afterwards self.h2 holds bandwidth^2
         and self.sqnorm the GLOBAL |phi|_F^2 (fp64), both on device; nothing syncs with the host.
 
         mark: optional callable(label) invoked between stages on the launching stream (bench.py records
-        HIP events there to time individual kernels).  Passing it selects the staged calls, which launch
-        exactly the kernels of the fused call.
+        HIP events there to time individual kernels).  Passing it selects the staged calls: the same kernels
+        as the fused call except that the median always takes the radix-select passes (the speculative
+        window of the fused call needs state that persists inside one workspace, see stein_common.h).
+        timing: single rank only -- keep the fused call and let the library record HIP events at its stage
+        boundaries (_lib.timing_reserve / _lib.timing_read).
         """
         st, n, d, nl = self.stages, self.n, self.d, self.n_local
         for name, t in (("theta", theta_local), ("score", score_local)):
@@ -215,7 +218,7 @@ class SvgdEngine:
                                  (name, self.dtype, nl, d, tuple(t.shape), t.dtype))
         if self.world == 1 and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
-                        self.flags)
+                        self.flags | (_lib.FLAG_TIMING if timing else 0))
             return self.phi
         if mark is None:
             def mark(label):

@@ -1,0 +1,105 @@
+"""GPU: the speculative median window of the fused single-rank call (stein_common.h: SpecState).
+
+The fused call predicts this step's median from the two previous steps, counts the distances below a narrow window around
+the prediction and selects the median inside the window; when the prediction fails it falls back to the radix-select
+passes.  Either way the bandwidth must be bit-identical to the staged calls (which always take the radix-select
+passes) on the same particles, at every step, and phi must agree to the last bit as well."""
+import numpy as np
+import pytest
+import torch
+
+from stein_amd import _lib
+from stein_amd.engine import SvgdEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def _spec_state(eng):
+    _, offs, _ = _lib.workspace_layout(eng.n_local, eng.n, eng.d, flags=eng.flags)
+    o = offs[_lib.WS_SELECT] + 64
+    u = eng.ws[o:o + 64].cpu().numpy().view(np.uint32)
+    return dict(magic=int(u[0]), center=int(u[1]), halfwidth=int(u[2]), lo_key=int(u[3]), width=int(u[4]),
+                count=int(u[5]), overflow=int(u[6]), hit=int(u[7]))
+
+
+def _same(a, b):
+    """elementwise equal, NaN == NaN (identical particles give h2 = 0 and NaN phi on every path, as in the reference)"""
+    return bool(((a == b) | (a.isnan() & b.isnan())).all())
+
+
+def _staged(eng, T, G):
+    return eng.compute_phi(T, G, mark=lambda label: None)
+
+
+@pytest.mark.parametrize("n,d,x3", [(2048, 32, True), (1001, 17, True), (1536, 64, False)])
+def test_window_hits_and_matches_radix_select(cuda, n, d, x3):
+    g = torch.Generator(device="cpu").manual_seed(n + d)
+    T = torch.randn(n, d, generator=g).to(cuda)
+    G = torch.randn(n, d, generator=g).to(cuda)
+    V = 1e-3 * torch.randn(n, d, generator=g).to(cuda)          # a steady drift, like a small optimizer step
+    fused, ref = SvgdEngine(n, d, device=cuda, x3=x3), SvgdEngine(n, d, device=cuda, x3=x3)
+    hits = []
+    for step in range(10):
+        phi = fused.compute_phi(T, G).clone()
+        h2 = fused.h2.clone()
+        phi_ref = _staged(ref, T, G)
+        torch.cuda.synchronize()
+        assert torch.equal(h2, ref.h2), "step %d: h2 %r vs %r (%r)" % (step, float(h2), float(ref.h2), _spec_state(fused))
+        assert torch.equal(phi, phi_ref)
+        assert torch.equal(fused.sqnorm, ref.sqnorm)
+        st = _spec_state(fused)
+        hits.append(st["hit"])
+        T = T + V * (1.0 + 0.05 * step)                          # slightly accelerating
+    assert hits[0] == 0                                           # no history yet: the radix passes ran
+    assert sum(hits[2:]) >= 6, hits                               # from the third step on the window carries the median
+
+
+def test_jump_and_degenerate_particles_fall_back(cuda):
+    n, d = 1024, 16
+    g = torch.Generator(device="cpu").manual_seed(5)
+    T = torch.randn(n, d, generator=g).to(cuda)
+    G = torch.randn(n, d, generator=g).to(cuda)
+    fused, ref = SvgdEngine(n, d, device=cuda), SvgdEngine(n, d, device=cuda)
+
+    def check(T, expect_hit=None):
+        phi = fused.compute_phi(T, G).clone()
+        phi_ref = _staged(ref, T, G)
+        torch.cuda.synchronize()
+        assert _same(fused.h2, ref.h2) and _same(phi, phi_ref)
+        st = _spec_state(fused)
+        if expect_hit is not None:
+            assert st["hit"] == expect_hit, st
+        return st
+
+    for k in range(4):
+        check(T * (1.0 + 1e-4 * k))
+    check(T * 3.0, expect_hit=0)                                  # the median jumps by 9x: outside any window
+    check(T * 3.0003)
+    st = check(T * 3.0006)
+    # all particles identical: every distance is 0, the window around the prediction cannot separate them
+    same = T[:1].expand(n, d).contiguous()
+    check(same, expect_hit=0)
+    check(same)
+    check(same)
+    # two clusters: the two middle order statistics straddle two different values (n*n even)
+    two = torch.cat([T[:1].expand(n // 2, d), (T[:1] + 1.0).expand(n // 2, d)]).contiguous()
+    for _ in range(4):
+        check(two)
+    # and back to a spread cloud
+    for k in range(4):
+        st = check(T * (1.0 + 1e-4 * k))
+    assert st["hit"] == 1
+
+
+def test_timing_flag_reports_every_stage(cuda):
+    n, d = 512, 32
+    T = torch.randn(n, d, device=cuda)
+    G = torch.randn(n, d, device=cuda)
+    eng = SvgdEngine(n, d, device=cuda)
+    _lib.timing_reserve(3)
+    for _ in range(4):                                            # the fourth call finds no free slot and is not timed
+        eng.compute_phi(T, G, timing=True)
+    calls = _lib.timing_read(8)
+    assert len(calls) == 3
+    for c in calls:
+        assert set(c) == set(_lib.T_STAGES) and all(v > 0.0 for v in c.values())
