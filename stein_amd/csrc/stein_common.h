@@ -56,29 +56,38 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// logical tile id -> (tile_m, tile_n) of the distance pass.
-//   SYM: upper triangle, row by row: row tm holds tiles (tm, tm..t-1); first id of row tm = tm*t - tm(tm-1)/2
-//   else: grouped order, 8 row tiles x all column tiles, inside each XCD's contiguous id range
+// logical workgroup id -> (tile_m, tile_n) of the distance pass; false = this id has no tile (it exits at once).
+// Tiles are walked in super-blocks of 8 x 8: the 64 tiles of a super-block are consecutive ids, so they run together
+// on one XCD (xcd_remap hands every XCD a contiguous id range) and share 8 A and 8 B operand tiles through its L2.
+// Walked row by row, every tile pulled its B operand from beyond the L2 (rocprofv3: 1 GB of fetches for a 17 MB operand).
+//   SYM: the super-blocks on or above the diagonal, row by row (row sm holds (sm, sm..S-1)); inside a diagonal
+//        super-block only tiles with tile_n >= tile_m exist
+//   else: all super-blocks, row by row
+constexpr int DSB = 8;
+__host__ __device__ __forceinline__ long distance_grid(bool sym, int tiles_m, int tiles_n) {
+  const long sm = (tiles_m + DSB - 1) / DSB, sn = (tiles_n + DSB - 1) / DSB;
+  return (sym ? sn * (sn + 1) / 2 : sm * sn) * (DSB * DSB);
+}
 template <bool SYM>
-__device__ __forceinline__ void distance_tile(int logical, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+__device__ __forceinline__ bool distance_tile(int logical, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  const int sb = logical / (DSB * DSB), in = logical % (DSB * DSB);
+  int sbm, sbn;
   if (SYM) {
-    const int t_ = tiles_n;
-    int tm = (int)(((2.0 * t_ + 1.0) - sqrt((2.0 * t_ + 1.0) * (2.0 * t_ + 1.0) - 8.0 * (double)logical)) * 0.5);
+    const int t_ = (tiles_n + DSB - 1) / DSB;
+    int tm = (int)(((2.0 * t_ + 1.0) - sqrt((2.0 * t_ + 1.0) * (2.0 * t_ + 1.0) - 8.0 * (double)sb)) * 0.5);
     tm = max(0, min(tm, t_ - 1));
-    while (tm > 0 && (long)tm * t_ - (long)tm * (tm - 1) / 2 > logical) --tm;
-    while ((long)(tm + 1) * t_ - (long)(tm + 1) * tm / 2 <= logical) ++tm;
-    tile_m = tm;
-    tile_n = tm + (logical - (int)((long)tm * t_ - (long)tm * (tm - 1) / 2));
+    while (tm > 0 && (long)tm * t_ - (long)tm * (tm - 1) / 2 > sb) --tm;
+    while ((long)(tm + 1) * t_ - (long)(tm + 1) * tm / 2 <= sb) ++tm;
+    sbm = tm;
+    sbn = tm + (sb - (int)((long)tm * t_ - (long)tm * (tm - 1) / 2));
   } else {
-    constexpr int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int g = logical / per_group;
-    const int first_m = g * GROUP;
-    const int gsize = min(tiles_m - first_m, GROUP);
-    const int in_g = logical - g * per_group;
-    tile_m = first_m + in_g % gsize;
-    tile_n = in_g / gsize;
+    const int sn = (tiles_n + DSB - 1) / DSB;
+    sbm = sb / sn;
+    sbn = sb % sn;
   }
+  tile_m = sbm * DSB + in / DSB;
+  tile_n = sbn * DSB + in % DSB;
+  return tile_m < tiles_m && tile_n < tiles_n && (!SYM || tile_n >= tile_m);
 }
 
 // ---- radix select: keys and state -----------------------------------------------------------------
@@ -177,7 +186,9 @@ template <bool MIRROR, bool PRED, bool DIAG, bool HIST, bool SPEC>
 __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int row0, int n_local, long ldD,
                                                        int tile_m, int brow0, u32 base, u64& packed, float two_s,
-                                                       SpecCtx& sx) {
+                                                       SpecCtx& sx, const float* rr, const float* rc) {
+  // rr / rc: LDS copies of the tile's 128 row norms and 128 column norms (0 outside the matrix).  Read from global
+  // memory here, the 66 dependent loads per thread were most of the epilogue's 35 k cycles.
   const long ntc = ldD >> 5;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
@@ -188,17 +199,18 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
     for (int j = 0; j < 2; ++j) {
       const int col = brow0 + wx * 64 + j * 32 + l31;
       const bool cok = !PRED || col < n;
-      const float rj = cok ? r[col] : 0.f;
+      const float rj = rc[wx * 64 + j * 32 + l31];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int lrow4 = tile_m * BM + wy * 64 + i * 32 + 8 * g + h4;  // first of 4 consecutive rows (e & 3)
+        const float4 ri4 = *reinterpret_cast<const float4*>(rr + wy * 64 + i * 32 + 8 * g + h4);
+        const float ris[4] = {ri4.x, ri4.y, ri4.z, ri4.w};
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int lrow = lrow4 + q;
           const bool rok = !PRED || lrow < n_local;
-          const float ri = rok ? r[row0 + lrow] : 0.f;
-          v[q] = (ri + rj) - two_s * acc[i][j][4 * g + q];
+          v[q] = (ris[q] + rj) - two_s * acc[i][j][4 * g + q];
           u32 w = MIRROR ? 2u : 1u;
           if (DIAG) w = lrow < col ? 2u : (lrow == col ? 1u : 0u);
           if (PRED && !(cok && rok)) w = 0u;
@@ -230,8 +242,8 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
   }
 }
 
-// `hl` is LDS that the caller no longer needs (all waves must be past their last LDS read): 8 KB for the histogram,
-// 8 KB + 64 B + 8 SPEC_QCAP B with a speculative window (spec != NULL, which needs hist0 != NULL).
+// `hl` is LDS that the caller no longer needs (all waves must be past their last LDS read): 8 KB histogram + 64 B +
+// 8 SPEC_QCAP B window queue + 1 KB row / column norms = 25152 B.  spec != NULL needs hist0 != NULL.
 template <bool SYM>
 __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                   float* __restrict__ D, int n, int row0, int n_local, long ldD,
@@ -249,6 +261,14 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u;
   sx.qcnt = hl + STEIN_HIST_BINS;                               // 16 u32 reserved
   sx.q = reinterpret_cast<u64*>(hl + STEIN_HIST_BINS + 16);
+  float* rr = reinterpret_cast<float*>(hl + STEIN_HIST_BINS + 16 + 2 * SPEC_QCAP);   // [128] row norms, [128] column norms
+  float* rc = rr + BM;
+  {
+    const int idx = t < BM ? tile_m * BM + t : brow0 + (t - BM);
+    const bool ok = t < BM ? idx < n_local : idx < n;
+    rr[t] = ok ? r[(t < BM ? row0 : 0) + idx] : 0.f;
+  }
+  if (!hist0) __syncthreads();
   if (hist0) {
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
     if (spec) {
@@ -267,13 +287,13 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   do {                                                                                                                 \
     if (hist0 && spec)                                                                                                 \
       distance_epilogue_body<MIRROR, PRED, DIAG, true, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,     \
-                                                             base, packed, two_s, sx);                                \
+                                                             base, packed, two_s, sx, rr, rc);                        \
     else if (hist0)                                                                                                    \
       distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
-                                                              base, packed, two_s, sx);                               \
+                                                              base, packed, two_s, sx, rr, rc);                       \
     else                                                                                                               \
       distance_epilogue_body<MIRROR, PRED, DIAG, false, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,   \
-                                                               base, packed, two_s, sx);                              \
+                                                               base, packed, two_s, sx, rr, rc);                      \
   } while (0)
   if (diag) STEIN_EPI(false, true, true);
   else if (edge) STEIN_EPI(SYM, true, false);

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
   unsigned char* As = smem;
   unsigned char* Bs = smem + XOPER;
   int tile_m, tile_n;
-  distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n);
+  if (!distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n)) return;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const long arow0 = row0 + (long)tile_m * BM, brow0 = (long)tile_n * BN;
@@ -390,22 +390,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
   const u16* __restrict__ pa1 = t3_chunk_ptr(T3, ntk, arow0 + (t >> 2) + 64, t & 3);
   const u16* __restrict__ pb0 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2), t & 3);
   const u16* __restrict__ pb1 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2) + 64, t & 3);
-  u32x4 ra[6], rb[6];
-  t3_load<NP>(pa0, pa1, 0, ra);
-  t3_load<NP>(pb0, pb1, 0, rb);
-  for (int kt = 0; kt < ntk; ++kt) {
-    x3_store_swz<NP>(As, t, ra);
-    x3_store_swz<NP>(Bs, t, rb);
+  // two register sets (X: even k tiles, Y: odd): a tile's loads are issued two tiles ahead, as soon as its set has been
+  // copied to LDS, so they have two MFMA phases to arrive (one phase was shorter than the L2 latency under load:
+  // 8 k cycles of every 22 k-cycle main loop went to waiting for them)
+  u32x4 raX[6], rbX[6], raY[6], rbY[6];
+#ifdef STEIN_STAMPS
+  u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
+  u64 st_last = __builtin_amdgcn_s_memtime();
+#endif
+  t3_load<NP>(pa0, pa1, 0, raX);
+  t3_load<NP>(pb0, pb1, 0, rbX);
+  if (ntk > 1) {
+    t3_load<NP>(pa0, pa1, 1, raY);
+    t3_load<NP>(pb0, pb1, 1, rbY);
+  }
+  for (int kt = 0; kt < ntk; kt += 2) {
+    x3_store_swz<NP>(As, t, raX);
+    x3_store_swz<NP>(Bs, t, rbX);
+    STAMP(0);   // waiting for the tile's loads + LDS stores
     __syncthreads();
-    if (kt + 1 < ntk) {
-      t3_load<NP>(pa0, pa1, kt + 1, ra);
-      t3_load<NP>(pb0, pb1, kt + 1, rb);
+    STAMP(1);   // barrier
+    if (kt + 2 < ntk) {
+      t3_load<NP>(pa0, pa1, kt + 2, raX);
+      t3_load<NP>(pb0, pb1, kt + 2, rbX);
     }
     x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
+    STAMP(2);   // load issue + fragment reads + MFMAs
     __syncthreads();
+    STAMP(1);
+    if (kt + 1 < ntk) {
+      x3_store_swz<NP>(As, t, raY);
+      x3_store_swz<NP>(Bs, t, rbY);
+      STAMP(0);
+      __syncthreads();
+      STAMP(1);
+      if (kt + 3 < ntk) {
+        t3_load<NP>(pa0, pa1, kt + 3, raY);
+        t3_load<NP>(pb0, pb1, kt + 3, rbY);
+      }
+      x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
+      STAMP(2);
+      __syncthreads();
+      STAMP(1);
+    }
   }
   distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, *two_s,
                          spec, spec_buf);
+#ifdef STEIN_STAMPS
+  STAMP(3);     // epilogue
+  if (t == 0) {
+    for (int k = 0; k < 4; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
+    atomicAdd(&g_stamps[7], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,7 +763,7 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
   const int ntk = (int)(L.x3_dk / 32);
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
   if (row0 + (int64_t)tiles_m * BM > L.x3_rows) return stein_fail(STEIN_E_SHAPE, "row block exceeds the padded planes");
-  const long nblk = symmetric ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
+  const long nblk = distance_grid(symmetric, tiles_m, tiles_n);
 #define X3_DIST(SYM, NP) launch_distance_x3<SYM, NP>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0, two_s, spec, spec_buf)
   switch (split_kind(dtype)) {
     case 1: if (symmetric) X3_DIST(true, 1); else X3_DIST(false, 1); break;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__
   float* Bs = smem + BM * LDK;
 
   int tile_m, tile_n;
-  distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n);
+  if (!distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n)) return;
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
@@ -815,7 +815,7 @@ static int distance_block_impl(const void* theta_all, const float* r_all, int64_
   if (sym && (row0 != 0 || n_local != n || (ld_dist & 63)))
     return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs the whole matrix (row0 = 0, n_local = n) and ld_dist %% 64 == 0");
   const int tiles_m = (int)((n_local + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
-  const long nblk = sym ? (long)tiles_n * (tiles_n + 1) / 2 : (long)tiles_m * tiles_n;
+  const long nblk = distance_grid(sym, tiles_m, tiles_n);
   if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
   hipStream_t s = (hipStream_t)stream;
   u64* h0 = (u64*)hist_level0;
