@@ -122,7 +122,7 @@ struct SpecState {
   u64 below;      // (unused: the weight below the window is summed from the slots at the head of the buffer)
   u64 total;      // n * n
   u32 last_key;   // key of the previous step's lower median target
-  u32 pad32;
+  u32 skip_l0;    // the level-0 histogram pass over D is not needed (taken in the distance epilogue, or the window hit)
   u64 pad;
 };
 static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
@@ -218,17 +218,17 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
             D[d_index(lrow, col, ntc)] = v[q];
             if (DIAG && w == 2u) D[d_index(col, lrow, ntc)] = v[q];
             if (HIST) {
-              const u32 key = f32_key(v[q]);
-              const u32 dg = key >> 21;
+              const u32 dg = f32_key(v[q]) >> 21;
               const u32 off = dg - base;
               if (off < 8u) packed += (u64)w << (8u * off);
               else atomicAdd(&hl[dg], w);
-              if (SPEC) {
-                sx.below += key < sx.lo ? w : 0u;
-                if (key - sx.lo <= sx.width) {   // rare: a fraction of a percent of the entries
-                  const u32 slot = atomicAdd(sx.qcnt, 1u);
-                  if (slot < SPEC_QCAP) sx.q[slot] = ((u64)key << 2) | w;
-                }
+            }
+            if (SPEC) {
+              const u32 key = f32_key(v[q]);
+              sx.below += key < sx.lo ? w : 0u;
+              if (key - sx.lo <= sx.width) {   // rare: a fraction of a percent of the entries
+                const u32 slot = atomicAdd(sx.qcnt, 1u);
+                if (slot < SPEC_QCAP) sx.q[slot] = ((u64)key << 2) | w;
               }
             }
           }
@@ -268,27 +268,32 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
     const bool ok = t < BM ? idx < n_local : idx < n;
     rr[t] = ok ? r[(t < BM ? row0 : 0) + idx] : 0.f;
   }
-  if (!hist0) __syncthreads();
-  if (hist0) {
+  // A step with a window (spec->width != 0) skips the level-0 histogram: it is only needed when the window misses,
+  // and then a k_hist<0> pass over D supplies it (SpecState::skip_l0).
+  const bool window = spec && spec->width != 0u;
+  const bool hist = hist0 && !window;
+  if (window) {
+    if (t == 0) { sx.qcnt[0] = 0u; sx.qcnt[2] = 0u; }
+    sx.lo = spec->lo_key;
+    sx.width = spec->width;
+  }
+  if (hist) {
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
-    if (spec) {
-      if (t == 0) { sx.qcnt[0] = 0u; sx.qcnt[2] = 0u; }
-      sx.lo = spec->lo_key;
-      sx.width = spec->width;
-    }
     __syncthreads();
     const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - two_s * acc[0][0][0];
     base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
     base = base < 3u ? 0u : base - 3u;  // window start
+  } else {
+    __syncthreads();
   }
   const bool diag = SYM && tile_m == tile_n;
   const bool edge = brow0 + BN > n || tile_m * BM + BM > n_local;
 #define STEIN_EPI(MIRROR, PRED, DIAG)                                                                                  \
   do {                                                                                                                 \
-    if (hist0 && spec)                                                                                                 \
-      distance_epilogue_body<MIRROR, PRED, DIAG, true, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,     \
-                                                             base, packed, two_s, sx, rr, rc);                        \
-    else if (hist0)                                                                                                    \
+    if (window)                                                                                                        \
+      distance_epilogue_body<MIRROR, PRED, DIAG, false, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
+                                                              base, packed, two_s, sx, rr, rc);                       \
+    else if (hist)                                                                                                     \
       distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
                                                               base, packed, two_s, sx, rr, rc);                       \
     else                                                                                                               \
@@ -299,7 +304,7 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   else if (edge) STEIN_EPI(SYM, true, false);
   else STEIN_EPI(SYM, false, false);
 #undef STEIN_EPI
-  if (hist0) {
+  if (hist) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       u32 c = (u32)(packed >> (8 * k)) & 255u;  // wave-sum of slot k, then one LDS atomic per wave
@@ -307,32 +312,33 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
       for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
       if (lane == 0 && c) atomicAdd(&hl[base + k], c);
     }
-    if (spec) {   // weight below the window: wave sum -> LDS -> one global atomic per workgroup, spread over slots
-      u32 b = sx.below;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
-      if (lane == 0 && b) atomicAdd(&sx.qcnt[2], b);
-    }
     __syncthreads();
-    if (spec && t == 0 && sx.qcnt[2])
-      atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + (blockIdx.x % SPEC_SLOTS) * 8),
-                (unsigned long long)sx.qcnt[2]);
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS)
       if (hl[b]) atomicAdd(&hist0[b], (u64)hl[b]);
-    if (spec) {   // flush the workgroup's queue to the global buffer
-      const u32 pushed = *sx.qcnt;
-      const u32 nq = min(pushed, SPEC_QCAP);
-      if (nq) {
-        __syncthreads();
-        if (t == 0) {
-          if (pushed > SPEC_QCAP) spec->overflow = 1u;
-          sx.qcnt[1] = atomicAdd(&spec->count, nq);
-        }
-        __syncthreads();
-        const u32 gbase = sx.qcnt[1];
-        for (u32 i = t; i < nq; i += NTHREADS)
-          if (gbase + i < SPEC_CAP) spec_buf[SPEC_SLOTS * 8 + gbase + i] = sx.q[i];
+  }
+  if (window) {
+    // weight below the window: wave sum -> LDS -> one global atomic per workgroup, spread over slots
+    u32 b = sx.below;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
+    if (lane == 0 && b) atomicAdd(&sx.qcnt[2], b);
+    __syncthreads();
+    if (t == 0 && sx.qcnt[2])
+      atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + (blockIdx.x % SPEC_SLOTS) * 8),
+                (unsigned long long)sx.qcnt[2]);
+    // flush the workgroup's queue to the global buffer
+    const u32 pushed = sx.qcnt[0];
+    const u32 nq = min(pushed, SPEC_QCAP);
+    if (nq) {
+      __syncthreads();
+      if (t == 0) {
+        if (pushed > SPEC_QCAP) spec->overflow = 1u;
+        sx.qcnt[1] = atomicAdd(&spec->count, nq);
       }
+      __syncthreads();
+      const u32 gbase = sx.qcnt[1];
+      for (u32 i = t; i < nq; i += NTHREADS)
+        if (gbase + i < SPEC_CAP) spec_buf[SPEC_SLOTS * 8 + gbase + i] = sx.q[i];
     }
   }
 }

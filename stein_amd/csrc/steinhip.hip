@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp
     sp->width = 0u;
   }
   sp->count = 0u; sp->overflow = 0u; sp->hit = 0u;
+  sp->skip_l0 = sp->width == 0u ? 1u : 0u;   // no window: the distance epilogue takes the level-0 histogram itself
   sp->below = 0ull; sp->total = total;
 }
 
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* s
     st->lo = flo; st->hi = fhi; st->median = med; st->h2 = h2;
     if (h2_out) *h2_out = h2;
     sp->hit = 1u;
+    sp->skip_l0 = 1u;
   }
 }
 
@@ -1070,7 +1072,9 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
                      (float)log((double)n), h2_out);
   LAUNCH_CHECK("k_spec_select");
   for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv) {
-    if (lv > 0 && (rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, &spec->hit))) return rc;
+    // level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it)
+    if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit)))
+      return rc;
     if ((rc = resolve_impl(hist, lv, n, sel, h2_out, nullptr, stream, &spec->hit))) return rc;
   }
   hipLaunchKernelGGL(k_spec_update, dim3(1), dim3(64), 0, s, (const SelState*)sel, spec);
