@@ -162,8 +162,12 @@ __device__ __forceinline__ int scale_exp(u32 maxbits, int lim) {
 }
 
 // column maxima of |X| [n][d] as bit patterns (non-negative floats order like unsigned integers)
+// blockIdx.z = 0: X0 -> cmax[0, dc), 1: X1 -> cmax[dc, 2 dc)
 template <typename TIN>
-__global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X, int n, int d, u32* __restrict__ cmax) {
+__global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
+                                                u32* __restrict__ cmax0, int dc) {
+  const TIN* __restrict__ X = blockIdx.z ? X1 : X0;
+  u32* __restrict__ cmax = cmax0 + (blockIdx.z ? dc : 0);
   __shared__ u32 red[4][64];
   const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
   const int col = blockIdx.x * 64 + cx;
@@ -212,10 +216,19 @@ __device__ __forceinline__ float load_as_f32(const u16* p) { return __uint_as_fl
 
 // TIN = float (KIND 2 or 3) or u16 = bf16 bits (KIND 1).  sc_all scales the row-major image, sc_col[c] column c of the
 // transposed one (both powers of two; 1 unless KIND 2).
+// blockIdx.z = 0: theta (row-major image R and transposed image Tt0), 1: score (transposed image Tt1 only; the grid is
+// sized for theta's padded extents, blocks outside the score's exit at once)
 template <typename TIN, int KIND>
-__global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X, int n, int d, u16* __restrict__ R, long r_rows,
-                                               int dk, u16* __restrict__ Tt, int dc, long nk,
-                                               const float* __restrict__ sc_all, const float* __restrict__ sc_col) {
+__global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
+                                               u16* __restrict__ R0, long r_rows, int dk, u16* __restrict__ Tt0,
+                                               u16* __restrict__ Tt1, int dc, long nk, const float* __restrict__ sc) {
+  const bool score = blockIdx.z != 0;
+  if (score && (blockIdx.x * 64 >= dc || (long)blockIdx.y * 64 >= nk)) return;
+  const TIN* __restrict__ X = score ? X1 : X0;
+  u16* __restrict__ R = score ? nullptr : R0;
+  u16* __restrict__ Tt = score ? Tt1 : Tt0;
+  const float* __restrict__ sc_all = sc + 4 * dc;                 // scale of the row-major theta image
+  const float* __restrict__ sc_col = sc + (score ? 0 : dc);       // per-column scales of this matrix
   __shared__ u16 tile[KIND][64][66];
   const int t = threadIdx.x;
   const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
@@ -709,13 +722,9 @@ static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score,
                          const SteinLayout& L, u16* T3, u16* Tt3, u16* Gt3, const float* sc) {
   const int64_t rows = L.x3_rows > L.x3_nk ? L.x3_rows : L.x3_nk;   // particle extent to cover (both multiples of 32)
   const int64_t cols = L.x3_dk > L.x3_dc ? L.x3_dk : L.x3_dc;      // parameter extent
-  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-  const dim3 grid_g((unsigned)((L.x3_dc + 63) / 64), (unsigned)((L.x3_nk + 63) / 64));
-  const int dc = (int)L.x3_dc;
-  hipLaunchKernelGGL((k_split<TIN, KIND>), grid, dim3(256), 0, stream, theta, (int)n, (int)d, T3, (long)L.x3_rows,
-                     (int)L.x3_dk, Tt3, dc, (long)L.x3_nk, sc + 4 * dc, sc + dc);
-  hipLaunchKernelGGL((k_split<TIN, KIND>), grid_g, dim3(256), 0, stream, score, (int)n, (int)d, (u16*)nullptr, 0l, 32,
-                     Gt3, dc, (long)L.x3_nk, (const float*)nullptr, sc);
+  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), 2u);
+  hipLaunchKernelGGL((k_split<TIN, KIND>), grid, dim3(256), 0, stream, theta, score, (int)n, (int)d, T3,
+                     (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc);
 }
 
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
@@ -731,9 +740,9 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
     HIP_TRY(hipMemsetAsync(cmax, 0, (size_t)2 * dc * sizeof(u32), stream));
     int gy = (int)((n + 63) / 64);
     if (gy > 256) gy = 256;
-    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy);
-    hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (int)n, (int)d, cmax);
-    hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)theta_all, (int)n, (int)d, cmax + dc);
+    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, 2u);
+    hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (const float*)theta_all,
+                       (int)n, (int)d, cmax, dc);
     LAUNCH_CHECK("k_colmax");
   }
   hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(256), 0, stream, cmax, dc, sc, kind == 2 ? PEXP_H2 : 0,

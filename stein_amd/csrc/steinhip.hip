@@ -126,7 +126,7 @@ __global__ void k_sel_init(SelState* st, u64 total) {
 //   here instead of re-reading D; a mirrored tile counts twice.
 // ------------------------------------------------------------------------------------------------
 template <bool VEC, bool SYM>
-__global__ __launch_bounds__(NTHREADS) void k_distance(const float* __restrict__ T, const float* __restrict__ r,
+__global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restrict__ T, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int d, int row0, int n_local,
                                                        long ldD, int tiles_m, int tiles_n, u64* __restrict__ hist0,
                                                        SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
