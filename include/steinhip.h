@@ -70,7 +70,7 @@ enum {
   STEIN_WS_PART_RS = 6,  /* float  [split][n_local]         partial rowsum(K)                     */
   STEIN_WS_SQPART = 7,   /* double [sq_blocks]              per-block partial |phi|^2             */
   STEIN_WS_SPEC = 8,     /* 16 MB  entries caught by the speculative median window (stein_svgd_phi only)  */
-  STEIN_WS_PLANES = 9,   /* split-bf16 operand planes (STEIN_FLAG_X3 only; empty otherwise), always last  */
+  STEIN_WS_PLANES = 9,   /* split-precision operand planes + scales (STEIN_FLAG_X3 only; empty otherwise), always last */
   STEIN_WS_NSECTIONS = 10
 };
 /* extra[] entries reported by stein_workspace_layout */
@@ -98,6 +98,12 @@ int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int
  *   sqnorm_out           : double[1], receives sum(phi_local^2) (the rank-local part of |phi|_F^2)
  *   K_out / dK_out       : optional (may be NULL): [n_local][n] float / [n_local][d] float
  * Valid only when n_local == n (one rank sees every row, so the median is global).
+ * The workspace carries state from one call to the next: the SELECT section keeps the median of the two previous
+ * calls and, from the third call on, the distance pass counts the entries below a narrow window around the
+ * extrapolated median and collects the entries inside it; when both median ranks fall inside the window an exact
+ * selection among the collected entries replaces the two radix-select passes over D, otherwise those run.  The
+ * result is identical either way (and for any workspace contents), only the time differs: keep ONE workspace per
+ * particle set.
  */
 int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int64_t d,
                    int64_t row0, int64_t n_local, int dtype,
@@ -111,7 +117,8 @@ int stein_svgd_phi(const void* theta_all, const void* score_all, int64_t n, int6
 int stein_rownorms(const void* theta_all, int64_t n, int64_t d, int dtype, float* r_out, void* stream);
 
 /* D[i][j] = r_i + r_j - 2 <theta_i, theta_j>, rows row0..row0+n_local, all n columns.
- * abstract_kernel.py:35.  dist_out has leading dimension ld_dist (>= n, multiple of 4).
+ * abstract_kernel.py:35.  dist_out is the tile-major distance image of leading dimension
+ * ld_dist (>= n, multiple of 64; take it from stein_workspace_layout), rows padded to a multiple of 128.
  * hist_level0: optional (NULL to skip) pointer to the level-0 histogram int64[2][2048] (zeroed by
  * stein_median_begin): the kernel adds the level-0 counts of the entries it produces, which replaces
  * stein_median_hist_pass(level 0).  flags: 0 or STEIN_STAGE_SYMMETRIC. */
@@ -120,11 +127,11 @@ int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, i
                          float* dist_out, int64_t ld_dist, void* hist_level0, const void* x3_planes, int flags,
                          void* stream);
 
-/* Split-bf16 mode (STEIN_FLAG_X3), staged form: fills the PLANES section (x3_planes = workspace +
- * offsets[STEIN_WS_PLANES], planes_bytes = total - offsets[STEIN_WS_PLANES]) with the three bf16 terms of every
- * entry of theta (row-major and transposed) and of the score (transposed).  Passing the same pointer as
- * `x3_planes` to stein_distance_block / stein_contract_partial / stein_kernel_contract selects the bf16-MFMA
- * kernels there; NULL selects the fp32-MFMA kernels.
+/* Split-precision mode (STEIN_FLAG_X3), staged form: fills the PLANES section (x3_planes = workspace +
+ * offsets[STEIN_WS_PLANES], planes_bytes = total - offsets[STEIN_WS_PLANES]) with the power-of-two scales and the
+ * 16-bit terms (see STEIN_FLAG_X3) of every entry of theta (row-major and transposed) and of the score (transposed).
+ * Passing the same pointer as `x3_planes` to stein_distance_block / stein_contract_partial / stein_kernel_contract
+ * selects the 16-bit-MFMA kernels there; NULL selects the fp32-MFMA kernels.
  * dtype = STEIN_BF16 (BASELINE config 2): theta_all / score_all hold bf16 values; they are the single operand plane,
  * K is rounded to bf16 once (its rowsum uses the rounded values), every product is one bf16 MFMA with fp32
  * accumulation.  bf16 inputs always need STEIN_FLAG_X3 / the planes. */

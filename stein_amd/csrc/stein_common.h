@@ -1,4 +1,4 @@
-// stein_common.h -- device helpers shared by the fp32-MFMA kernels (steinhip.hip) and the split-bf16
+// stein_common.h -- device helpers shared by the fp32-MFMA kernels (steinhip.hip) and the split-precision
 // kernels (stein_x3.hip): tile geometry, tile-id mapping, radix-select keys/state, and the two epilogues.
 #pragma once
 
@@ -383,7 +383,7 @@ struct SteinLayout {
   size_t off[STEIN_WS_NSECTIONS];
   size_t total;
   int64_t ld_dist, split, sq_blocks, jchunk, tiles_m, cblocks;
-  // split-bf16 planes (flags & STEIN_FLAG_X3): ushort [3][rows][k] each
+  // split-precision planes (flags & STEIN_FLAG_X3): 16-bit [3 slots][rows][k] each, tile-major
   int64_t x3_rows, x3_dk;   // row-major theta planes: x3_rows x x3_dk  (distance operands)
   int64_t x3_dc, x3_nk;     // transposed planes of theta and of the score: x3_dc x x3_nk  (contraction B operand)
   size_t x3_t3, x3_tt3, x3_gt3;  // byte offsets inside the PLANES section

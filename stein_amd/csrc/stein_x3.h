@@ -1,4 +1,4 @@
-// stein_x3.h -- host entry points of the split-bf16 ("x3") kernels in stein_x3.hip.
+// stein_x3.h -- host entry points of the split-precision ("x3") kernels in stein_x3.hip.
 #pragma once
 #include "stein_common.h"
 

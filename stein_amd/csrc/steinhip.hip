@@ -683,7 +683,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
   // workgroups per unit of split and resident workgroups per round: the fp32 kernel tiles [G | theta] in 128-column
-  // blocks at 3 workgroups per CU; the split-bf16 kernel pairs the blocks up (256 columns) at 1 workgroup per CU
+  // blocks at 3 workgroups per CU; the split-precision kernel pairs the blocks up (256 columns) at 1 workgroup per CU
   const bool x3 = (flags & STEIN_FLAG_X3) != 0;
   const int64_t base = x3 ? L->tiles_m * L->cblocks : L->tiles_m * 2 * L->cblocks;
   const int64_t jt = (n + BK - 1) / BK;  // j tiles

@@ -125,9 +125,9 @@ class SvgdEngine:
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("dtype must be torch.float32 or torch.bfloat16")
         self.dtype = dtype
-        # x3 (default): both GEMMs run on the bf16 matrix cores with every fp32 operand split into three bf16
-        # terms -- fp32-level accuracy at a fraction of the fp32-MFMA time.  x3=False (or STEIN_X3=0) selects the
-        # fp32-input MFMA kernels (an exact k-ordered fmaf chain).
+        # x3 (default): both GEMMs run on the 16-bit matrix cores with every fp32 operand scaled by a power of two and
+        # split into two fp16 terms -- fp32-level accuracy at a fraction of the fp32-MFMA time (stein_x3.hip).
+        # x3=False (or STEIN_X3=0) selects the fp32-input MFMA kernels (an exact k-ordered fmaf chain).
         if x3 is None:
             x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
         self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
@@ -191,7 +191,7 @@ class SvgdEngine:
 
     @property
     def planes(self):
-        """split-bf16 operand planes (None unless x3)"""
+        """split-precision operand planes and scales (None unless x3)"""
         if not self.x3:
             return None
         o = self._offs[_lib.WS_PLANES]

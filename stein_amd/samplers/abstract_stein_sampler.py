@@ -41,7 +41,7 @@ class AbstractSteinSampler:
                       fp32 placeholders do, stein/kernels/abstract_kernel.py:31).
         kernel_dtype: torch.float32 (default) or torch.bfloat16 -- what theta and the score are rounded to when they
                       are fed to the kernel / contraction (the reference rounds fp64 -> fp32 at that point).
-        x3          : None (default: split-bf16 GEMMs) / False (fp32-input MFMA GEMMs); see engine.SvgdEngine.
+        x3          : None (default: split-fp16 GEMMs on the 16-bit matrix cores) / False (fp32-input MFMA GEMMs); see engine.SvgdEngine.
         """
         self.n_particles = int(n_particles)
         self.log_p = log_p

@@ -1,4 +1,4 @@
-"""Stage-by-stage parity of the fp32-MFMA HIP path (x3=False; the split-bf16 default is covered by test_gpu_x3.py)
+"""Stage-by-stage parity of the fp32-MFMA HIP path (x3=False; the split-precision default is covered by test_gpu_x3.py)
 through the C ABI against the CPU oracle.
 
 Tolerances (north star: 1e-5 relative, fp32):
