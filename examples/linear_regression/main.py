@@ -17,6 +17,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from stein_amd.optimizers import AdamGradientDescent  # noqa: E402
 from stein_amd.samplers import SteinSampler  # noqa: E402
+from stein_amd.scores import GlmScore  # noqa: E402
 
 
 def make_data(n_samples=1000, n_feats=1, seed=0):
@@ -38,11 +39,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--particles", type=int, default=50)
     ap.add_argument("--iters", type=int, default=500)
+    ap.add_argument("--autograd", action="store_true", help="differentiate log_posterior with torch instead of the HIP score producer")
     args = ap.parse_args()
     X, y, w_true = make_data()
     feed = {"X": torch.tensor(X, dtype=torch.float32, device="cuda"),
             "y": torch.tensor(y, dtype=torch.float32, device="cuda")}
-    sampler = SteinSampler(args.particles, log_posterior, AdamGradientDescent(learning_rate=1e-1),
+    score = None if args.autograd else GlmScore("linear", X.shape[1])
+    sampler = SteinSampler(args.particles, log_posterior, AdamGradientDescent(learning_rate=1e-1), score=score,
                            model_vars={"model/w:0": [X.shape[1], 1]})
     t0 = time.time()
     for _ in range(args.iters):

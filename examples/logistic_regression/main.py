@@ -3,7 +3,10 @@ examples/logistic_regression/main.py: hierarchical prior w ~ N(0, 1/alpha), alph
 log alpha, minibatches of 50 rescaled to the training-set size, 100 particles, Adam(0.1).  The Covertype file the
 reference reads is not shipped with it, so the data here are synthetic with the same shape (54 features).
 
-    python examples/logistic_regression/main.py [--particles 100] [--iters 2000]
+    python examples/logistic_regression/main.py [--particles 100] [--iters 2000] [--autograd]
+
+The score matrix comes from the HIP score producer (stein_amd.scores.GlmScore, the closed-form gradient of the model
+below); --autograd differentiates log_posterior with torch instead.
 """
 import argparse
 import os
@@ -16,6 +19,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from stein_amd.optimizers import AdamGradientDescent  # noqa: E402
 from stein_amd.samplers import SteinSampler  # noqa: E402
+from stein_amd.scores import GlmScore  # noqa: E402
 
 
 def make_data(n=20000, n_feats=54, seed=0):
@@ -47,13 +51,16 @@ def main():
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=50)
+    ap.add_argument("--autograd", action="store_true", help="differentiate log_posterior with torch instead of the HIP score producer")
     args = ap.parse_args()
     (Xtr, ytr), (Xte, yte) = make_data()
     dev = "cuda"
     Xtr_t, ytr_t = torch.tensor(Xtr, dtype=torch.float32, device=dev), torch.tensor(ytr, dtype=torch.float32, device=dev)
     Xte_t = torch.tensor(Xte, dtype=torch.float32, device=dev)
+    # packed columns follow the sorted variable names: log_alpha first, then the weights
+    score = None if args.autograd else GlmScore("logistic", Xtr.shape[1], w_col=1, alpha_col=0, n_train=len(Xtr))
     sampler = SteinSampler(args.particles, make_log_posterior(len(Xtr), args.batch),
-                           AdamGradientDescent(learning_rate=1e-1),
+                           AdamGradientDescent(learning_rate=1e-1), score=score,
                            model_vars={"model/w:0": [Xtr.shape[1], 1], "model/log_alpha:0": []})
     gen = torch.Generator(device=dev).manual_seed(0)
 

@@ -215,6 +215,24 @@ int stein_apply_adam(void* theta, const float* phi, void* mu, void* nu, int64_t 
                      double lr, double beta1, double beta2, double eps, int64_t t,
                      void* step_out, void* stream);
 
+/* ---- score producers (the step before the hot path) ------------------------------
+ * d log p / d theta of every particle for the generalised linear models of the reference's examples, in one launch;
+ * replaces the n sequential sess.run(grad_log_p) calls of SteinSampler.train_on_batch
+ * (stein/samplers/stein_sampler.py:59-68) for these models.
+ *   theta [n][d] float   particle i holds the weights w at columns w_col .. w_col + n_feats and, when alpha_col >= 0,
+ *                        log(alpha) at column alpha_col; any other column gets score 0
+ *   X [batch][n_feats], y [batch] float (device)
+ *   STEIN_GLM_LINEAR    examples/linear_regression/main.py:18-31:  log p = -1/2 sum_b (x_b.w - y_b)^2 + log prior
+ *   STEIN_GLM_LOGISTIC  examples/logistic_regression/main.py:23-49: log p = scale * sum_b [y_b z_b - softplus(z_b)] + log prior,
+ *                       z = X w, scale = n_train / n_batch
+ *   prior: alpha_col < 0: w ~ N(0, 1 / prior_precision);  alpha_col >= 0: w ~ N(0, 1 / alpha), alpha ~ Gamma(1, gamma_rate)
+ *          evaluated at alpha = exp(theta[alpha_col]) without a Jacobian term, as the reference does
+ *   score [n][d] float   d/dw_c = scale * sum_b resid_b x_bc - precision * w_c;  d/dlog alpha = F/2 - alpha (sum w^2 / 2 + rate) */
+enum { STEIN_GLM_LINEAR = 0, STEIN_GLM_LOGISTIC = 1 };
+int stein_score_glm(const float* theta, int64_t n, int64_t d, int kind, int64_t w_col, int64_t n_feats, int64_t alpha_col,
+                    const float* X, const float* y, int64_t batch, double scale, double prior_precision,
+                    double gamma_rate, float* score, void* stream);
+
 /* small helpers used by the host layer */
 int stein_cast_f64_to_f32(const double* src, float* dst, int64_t count, void* stream);
 int stein_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);

@@ -21,6 +21,7 @@ HIST_BINS, HIST_LEVELS = 2048, 3
 STAGE_SYMMETRIC = 1
 FLAG_X3 = 1
 FLAG_TIMING = 4
+GLM_LINEAR, GLM_LOGISTIC = 0, 1
 T_STAGES = ("prepare", "distance", "median", "contract", "finish")   # STEIN_T_* of include/steinhip.h
 
 _c = ctypes
@@ -30,6 +31,7 @@ _vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.
 _SIGNATURES = {
     "stein_workspace_bytes": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz)],
     "stein_workspace_layout": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz), _c.POINTER(_i64)],
+    "stein_score_glm": [_vp, _i64, _i64, _int, _i64, _i64, _i64, _vp, _vp, _i64, _dbl, _dbl, _dbl, _vp, _vp],
     "stein_timing_reserve": [_int],
     "stein_timing_read": [_c.POINTER(_c.c_float), _int, _c.POINTER(_int)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],

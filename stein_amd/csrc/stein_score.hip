@@ -1,0 +1,144 @@
+// stein_score.hip -- score producers on the device: d log p / d theta for every particle, for the generalised
+// linear models of the reference's examples.  This is the step immediately BEFORE the hot path: the reference
+// obtains the score matrix with n sequential sess.run(grad_log_p) calls (stein/samplers/stein_sampler.py:59-68)
+// on a TensorFlow graph of the model; here one launch writes the [n][d] score matrix that stein_svgd_phi consumes.
+//
+// Models (theta packs the weights w [F] and, for the hierarchical prior, log alpha):
+//   linear    examples/linear_regression/main.py:18-31
+//               log p = -1/2 sum_b (x_b.w - y_b)^2 + sum_c log N(w_c; 0, 1)
+//               d/dw_c = scale * sum_b (y_b - x_b.w) x_bc - prec * w_c              (scale = 1, prec = 1 there)
+//   logistic  examples/logistic_regression/main.py:23-49
+//               log p = scale * sum_b [y_b z_b - softplus(z_b)],  z = X w,  scale = n_train / n_batch
+//                       + sum_c log N(w_c; 0, alpha^-1/2) + log Gamma(alpha; 1, rate)   (density at alpha, no Jacobian)
+//               d/dw_c       = scale * sum_b (y_b - sigmoid(z_b)) x_bc - alpha w_c
+//               d/dlog alpha = F/2 - alpha (1/2 sum_c w_c^2 + rate)
+//
+// LP lanes per particle (64 / LP particles per wave), lanes over the features (w and the gradient stay in registers),
+// the batch X staged in LDS and read by every particle group of a wave at the same address (broadcast).
+#include "stein_common.h"
+
+constexpr int SC_MAXLDS = 15 * 1024;   // floats of X per LDS chunk (60 KB) + its y values
+
+template <int LP>
+__device__ __forceinline__ float group_sum(float v) {   // sum over the LP consecutive lanes of a particle
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// KF = features per lane, LP = lanes per particle (F <= LP * KF)
+template <int KF, int LP>
+__global__ __launch_bounds__(256) void k_score_glm(const float* __restrict__ theta, int n, int d, int kind, int w_col,
+                                                   int F, int alpha_col, const float* __restrict__ X,
+                                                   const float* __restrict__ y, int B, int chunk_rows, float scale,
+                                                   float prior_precision, float gamma_rate, float* __restrict__ score) {
+  extern __shared__ float lds[];   // [chunk_rows][F] X, then [chunk_rows] y
+  float* xs = lds;
+  float* ys = lds + (size_t)chunk_rows * F;
+  constexpr int PPB = 4 * (64 / LP);   // particles per workgroup pass
+  const int t = threadIdx.x, lane = t % LP, sub = t / LP;
+  const int nchunks = (B + chunk_rows - 1) / chunk_rows;
+  auto stage = [&](int c0) {
+    const int rows = min(chunk_rows, B - c0);
+    for (int i = t; i < rows * F; i += 256) xs[i] = X[(size_t)c0 * F + i];
+    for (int i = t; i < rows; i += 256) ys[i] = y[c0 + i];
+  };
+  if (nchunks == 1) {   // the whole batch fits: stage it once for every particle this workgroup handles
+    stage(0);
+    __syncthreads();
+  }
+  for (long p0 = (long)blockIdx.x * PPB; p0 < n; p0 += (long)gridDim.x * PPB) {
+    const long p = p0 + sub;
+    const bool live = p < n;
+    const float* th = theta + (size_t)(live ? p : 0) * d;
+    float w[KF], g[KF];
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+      const int c = lane + LP * k;
+      w[k] = (live && c < F) ? th[w_col + c] : 0.f;
+      g[k] = 0.f;
+    }
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (nchunks > 1) {
+        __syncthreads();
+        stage(ch * chunk_rows);
+        __syncthreads();
+      }
+      const int rows = min(chunk_rows, B - ch * chunk_rows);
+      for (int b = 0; b < rows; ++b) {
+        const float* xb = xs + (size_t)b * F;
+        float xv[KF], part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+          const int c = lane + LP * k;
+          xv[k] = c < F ? xb[c] : 0.f;
+          part = fmaf(w[k], xv[k], part);
+        }
+        const float z = group_sum<LP>(part);
+        const float r = kind == STEIN_GLM_LOGISTIC ? ys[b] - 1.f / (1.f + expf(-z)) : ys[b] - z;
+#pragma unroll
+        for (int k = 0; k < KF; ++k) g[k] = fmaf(r, xv[k], g[k]);
+      }
+    }
+    float prec = prior_precision, sw2 = 0.f;
+    if (alpha_col >= 0) {
+      prec = expf(live ? th[alpha_col] : 0.f);
+#pragma unroll
+      for (int k = 0; k < KF; ++k) sw2 = fmaf(w[k], w[k], sw2);
+      sw2 = group_sum<LP>(sw2);
+    }
+    if (live) {
+      float* out = score + (size_t)p * d;
+      for (int c = lane; c < d; c += LP) {   // columns that are neither weights nor log alpha carry no gradient
+        if (c < w_col || c >= w_col + F) out[c] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KF; ++k) {
+        const int c = lane + LP * k;
+        if (c < F) out[w_col + c] = scale * g[k] - prec * w[k];
+      }
+      if (alpha_col >= 0 && lane == 0) out[alpha_col] = 0.5f * (float)F - prec * (0.5f * sw2 + gamma_rate);
+    }
+  }
+}
+
+extern "C" int stein_score_glm(const float* theta, int64_t n, int64_t d, int kind, int64_t w_col, int64_t n_feats,
+                               int64_t alpha_col, const float* X, const float* y, int64_t batch, double scale,
+                               double prior_precision, double gamma_rate, float* score, void* stream) {
+  if (!theta || !X || !y || !score) return stein_fail(STEIN_E_BADARG, "NULL pointer");
+  if (kind != STEIN_GLM_LINEAR && kind != STEIN_GLM_LOGISTIC) return stein_fail(STEIN_E_BADARG, "kind %d", kind);
+  if (n < 1 || d < 1 || batch < 1 || n_feats < 1 || n > 0x7fffffffl || d > 0x7fffffffl || batch > 0x7fffffffl)
+    return stein_fail(STEIN_E_SHAPE, "bad shape n=%lld d=%lld batch=%lld F=%lld", (long long)n, (long long)d,
+                      (long long)batch, (long long)n_feats);
+  if (w_col < 0 || w_col + n_feats > d || alpha_col >= d || (alpha_col >= w_col && alpha_col < w_col + n_feats))
+    return stein_fail(STEIN_E_SHAPE, "weights [%lld, %lld) / log-alpha column %lld do not fit d=%lld", (long long)w_col,
+                      (long long)(w_col + n_feats), (long long)alpha_col, (long long)d);
+  if (n_feats > 1024) return stein_fail(STEIN_E_UNSUPPORTED, "more than 1024 features per particle");
+  int64_t chunk_rows = SC_MAXLDS / (n_feats + 1);
+  if (chunk_rows > batch) chunk_rows = batch;
+  const size_t lds_bytes = (size_t)chunk_rows * (n_feats + 1) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  // 16 lanes per particle (4 particles per wave: a quarter of the reduction steps per particle) up to 256 features
+  const int lp = n_feats <= 256 ? 16 : 64;
+  const int ppb = 4 * (64 / lp);
+  long blocks = (long)((n + ppb - 1) / ppb);
+  if (blocks > 2048) blocks = 2048;
+  const int kf = (int)((n_feats + lp - 1) / lp);
+#define SC_LAUNCH(KF, LP)                                                                                            \
+  hipLaunchKernelGGL((k_score_glm<KF, LP>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, theta, (int)n, (int)d,   \
+                     kind, (int)w_col, (int)n_feats, (int)alpha_col, X, y, (int)batch, (int)chunk_rows, (float)scale, \
+                     (float)prior_precision, (float)gamma_rate, score)
+  if (lp == 16) {
+    if (kf <= 1) SC_LAUNCH(1, 16);
+    else if (kf <= 2) SC_LAUNCH(2, 16);
+    else if (kf <= 4) SC_LAUNCH(4, 16);
+    else if (kf <= 8) SC_LAUNCH(8, 16);
+    else SC_LAUNCH(16, 16);
+  } else {
+    if (kf <= 8) SC_LAUNCH(8, 64);
+    else SC_LAUNCH(16, 64);
+  }
+#undef SC_LAUNCH
+  LAUNCH_CHECK("k_score_glm");
+  return STEIN_OK;
+}

@@ -31,6 +31,10 @@ class SteinSampler(AbstractSteinSampler):
     def score_matrix(self, batch_feed=None):
         """[n_local, d] float32 device tensor of d log_p / d theta for every particle."""
         if self.score is not None:
+            if getattr(self.score, "wants_matrix", False):   # device score producers (stein_amd.scores) take the packed matrix
+                if self.dtype != torch.float32:
+                    raise ValueError("device score producers need float32 particles")
+                return self.score(self.theta_matrix, batch_feed)
             arg = self.theta if self._access is not None else self.theta_matrix
             g = self.score(arg, batch_feed)
             if isinstance(g, dict):
