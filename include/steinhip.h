@@ -127,6 +127,30 @@ int stein_distance_block(const void* theta_all, const float* r_all, int64_t n, i
                          float* dist_out, int64_t ld_dist, void* hist_level0, const void* x3_planes, int flags,
                          void* stream);
 
+/* Speculative median window, staged form for several ranks (stein_svgd_phi does the same inside one call; the state
+ * and the idea are described there).  Every rank keeps its own SELECT and SPEC sections; they stay identical because
+ * every rank sees the same medians.  Per step, on every rank:
+ *   stein_spec_begin            instead of stein_median_begin: zeroes the histograms, sets the ranks and this step's window
+ *   stein_distance_block_spec   stein_distance_block that also counts the weight below the window and collects the
+ *                               entries inside it (and then does NOT fill hist_level0: state word `skip_l0` = 0)
+ *   stein_spec_tally            entries -> table of SPEC table words (uint64): [0] weight below, [1] != 0: invalid,
+ *                               [8 + k] weight of the k-th key of the window; the table is 65544 uint64 starting
+ *                               2^21 uint64 into the SPEC section
+ *   all-reduce(sum) of the table over the ranks (host)
+ *   stein_spec_pick             both median targets from the summed table: sets h2 / median and the state word `hit`;
+ *                               when `hit` stays 0 (read it back: uint32 at select_state + 64 + 28, `skip_l0` at + 52)
+ *                               run the radix-select calls: stein_median_hist_pass(level 0) if skip_l0 == 0, then
+ *                               all-reduce / stein_median_resolve / levels 1, 2 as usual
+ *   stein_spec_update           after the median is final either way: predict the next step's window */
+int stein_spec_begin(void* hist, void* select_state, void* spec_buf, int64_t total, void* stream);
+int stein_distance_block_spec(const void* theta_all, const float* r_all, int64_t n, int64_t d,
+                              int64_t row0, int64_t n_local, int dtype,
+                              float* dist_out, int64_t ld_dist, void* hist_level0, const void* x3_planes, int flags,
+                              void* select_state, void* spec_buf, void* stream);
+int stein_spec_tally(void* select_state, void* spec_buf, void* stream);
+int stein_spec_pick(void* select_state, void* spec_buf, int64_t n, float* h2_out, float* median_out, void* stream);
+int stein_spec_update(void* select_state, void* stream);
+
 /* Split-precision mode (STEIN_FLAG_X3), staged form: fills the PLANES section (x3_planes = workspace +
  * offsets[STEIN_WS_PLANES], planes_bytes = total - offsets[STEIN_WS_PLANES]) with the power-of-two scales and the
  * 16-bit terms (see STEIN_FLAG_X3) of every entry of theta (row-major and transposed) and of the score (transposed).

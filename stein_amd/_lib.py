@@ -22,6 +22,9 @@ STAGE_SYMMETRIC = 1
 FLAG_X3 = 1
 FLAG_TIMING = 4
 GLM_LINEAR, GLM_LOGISTIC = 0, 1
+SPEC_TABLE_WORDS = 65544          # uint64 words of the rank-summed window table ...
+SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC section (slots + entry buffer)
+SPEC_HIT_OFFSET, SPEC_SKIP_L0_OFFSET = 64 + 28, 64 + 52   # uint32 state words inside the SELECT section
 T_STAGES = ("prepare", "distance", "median", "contract", "finish")   # STEIN_T_* of include/steinhip.h
 
 _c = ctypes
@@ -31,6 +34,11 @@ _vp, _i64, _int, _dbl, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.
 _SIGNATURES = {
     "stein_workspace_bytes": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz)],
     "stein_workspace_layout": [_i64, _i64, _i64, _int, _int, _c.POINTER(_sz), _c.POINTER(_i64)],
+    "stein_spec_begin": [_vp, _vp, _vp, _i64, _vp],
+    "stein_distance_block_spec": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _int, _vp, _vp, _vp],
+    "stein_spec_tally": [_vp, _vp, _vp],
+    "stein_spec_pick": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "stein_spec_update": [_vp, _vp],
     "stein_score_glm": [_vp, _i64, _i64, _int, _i64, _i64, _i64, _vp, _vp, _i64, _dbl, _dbl, _dbl, _vp, _vp],
     "stein_timing_reserve": [_int],
     "stein_timing_read": [_c.POINTER(_c.c_float), _int, _c.POINTER(_int)],

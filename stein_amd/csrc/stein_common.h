@@ -132,6 +132,13 @@ constexpr u32 SPEC_CAP = (1u << 21) - 2048u;   // global buffer capacity (entrie
 constexpr u32 SPEC_SLOTS = 256;                 // 256 "below" counters, one per 64-byte line (8 u64 apart): every
                                                 // workgroup adding to ONE address serialised at the L2 (+165 us)
 constexpr u32 SPEC_HW_MAX = 32767;       // window <= 65535 keys: two 8-bit selection passes
+// Several ranks (staged calls): every rank tallies its window entries into one counter per key of the window,
+// the tables are summed over the ranks and every rank picks the targets from the sum (one all-reduce of
+// SPEC_TABLE u64).  Behind the entry buffer: [0] weight below the window, [1] invalid (no window / overflow),
+// [2] entries, [8 + k] weight of key lo_key + k.
+constexpr u32 SPEC_TABLE_HDR = 8;
+constexpr u32 SPEC_TABLE = SPEC_TABLE_HDR + 2 * SPEC_HW_MAX + 2;   // 65544 u64
+static_assert(SPEC_SLOTS * 8 + SPEC_CAP == (1u << 21), "the table starts 2^21 words into the SPEC section (stein_amd/_lib.py)");
 
 __device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
   const u32 u = __float_as_uint(x);

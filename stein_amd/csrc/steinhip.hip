@@ -403,6 +403,82 @@ __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* s
   }
 }
 
+// ---- the window across several ranks: tally -> all-reduce(sum) -> pick ---------------------------------------------
+// this rank's window entries -> one counter per key (table[SPEC_TABLE_HDR + key - lo_key]); workgroup 0 also fills the header
+__global__ __launch_bounds__(256) void k_spec_tally(const SpecState* __restrict__ sp, const u64* __restrict__ slots,
+                                                    u64* __restrict__ table) {
+  const u64* __restrict__ buf = slots + SPEC_SLOTS * 8;
+  const u32 cnt = sp->count, lo = sp->lo_key;
+  const bool bad = sp->width == 0u || sp->overflow || cnt > SPEC_CAP;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < (int)SPEC_SLOTS && slots[threadIdx.x * 8])
+      atomicAdd(reinterpret_cast<unsigned long long*>(&table[0]), (unsigned long long)slots[threadIdx.x * 8]);
+    if (threadIdx.x == 0) {
+      if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(&table[1]), 1ull);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&table[2]), (unsigned long long)cnt);
+    }
+  }
+  if (bad) return;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    const u64 e = buf[i];
+    atomicAdd(reinterpret_cast<unsigned long long*>(&table[SPEC_TABLE_HDR + ((u32)(e >> 2) - lo)]),
+              (unsigned long long)(e & 3ull));
+  }
+}
+
+// one workgroup: the two median targets from the rank-summed table (identical on every rank)
+__global__ __launch_bounds__(1024) void k_spec_pick(SelState* st, SpecState* sp, const u64* __restrict__ table,
+                                                    float ln_n, float* h2_out, float* median_out) {
+  __shared__ u64 part[1024];
+  __shared__ u32 found[2];
+  const int t = threadIdx.x;
+  const u32 width = sp->width, lo = sp->lo_key;
+  if (width == 0u || table[1] != 0ull) return;   // miss on every rank alike
+  const u64 total = sp->total, below = table[0];
+  const u64 r0 = (total & 1ull) ? total / 2 : total / 2 - 1, r1 = total / 2;
+  if (r0 < below) return;
+  constexpr int PER = 64;   // 1024 threads x 64 keys >= 65536
+  u64 mine = 0ull;
+  for (int k = 0; k < PER; ++k) {
+    const u32 key = (u32)t * PER + k;
+    if (key <= width) mine += table[SPEC_TABLE_HDR + key];
+  }
+  part[t] = mine;
+  if (t < 2) found[t] = 0xffffffffu;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
+    u64 v = 0ull;
+    if (t >= o) v = part[t - o];
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const u64 excl = part[t] - mine;
+  for (int tg = 0; tg < 2; ++tg) {
+    const u64 rank = (tg ? r1 : r0) - below;
+    if (excl <= rank && rank < excl + mine) {
+      u64 cum = excl;
+      for (int k = 0; k < PER; ++k) {
+        const u64 c = table[SPEC_TABLE_HDR + (u32)t * PER + k];
+        if (rank < cum + c) { found[tg] = (u32)t * PER + k; break; }
+        cum += c;
+      }
+    }
+  }
+  __syncthreads();
+  if (t == 0 && found[0] != 0xffffffffu && found[1] != 0xffffffffu) {
+    const float flo = key_f32(lo + found[0]), fhi = key_f32(lo + found[1]);
+    const float med = st->even ? 0.5f * (flo + fhi) : flo;
+    const float bw = sqrtf(med / ln_n);      // abstract_kernel.py:40
+    const float h2 = bw * bw;                // squared_exponential_kernel.py:22 squares it again
+    st->lo = flo; st->hi = fhi; st->median = med; st->h2 = h2;
+    if (h2_out) *h2_out = h2;
+    if (median_out) *median_out = med;
+    sp->hit = 1u;
+    sp->skip_l0 = 1u;
+  }
+}
+
 // after the median is final (window or radix passes): predict the next one and size its window
 __global__ void k_spec_update(const SelState* st, SpecState* sp) {
   if (threadIdx.x || blockIdx.x) return;
@@ -723,7 +799,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   put(STEIN_WS_PART_T, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_RS, (size_t)split * n_local * 4);
   put(STEIN_WS_SQPART, (size_t)sqb * 8);
-  put(STEIN_WS_SPEC, ((size_t)SPEC_CAP + SPEC_SLOTS * 8) * 8);
+  put(STEIN_WS_SPEC, ((size_t)SPEC_CAP + SPEC_SLOTS * 8 + SPEC_TABLE) * 8);   // slots | entries | rank-summed table
   // split operand planes: always LAST so the offsets above do not depend on the flag
   L->x3_rows = (int64_t)align_up((size_t)n, 128) + 128;   // a rank's last row tile may start past roundup(n, 128) - 128
   L->x3_dk = (int64_t)align_up((size_t)d, 32);
@@ -904,6 +980,57 @@ static int resolve_impl(const void* hist, int level, int64_t n, void* select_sta
 extern "C" int stein_median_resolve(const void* hist, int level, int64_t n, void* select_state, float* h2_out,
                                     float* median_out, void* stream) {
   return resolve_impl(hist, level, n, select_state, h2_out, median_out, stream, nullptr);
+}
+
+// ---- speculative window, staged form (several ranks; include/steinhip.h) -------------------------------------------
+static inline SpecState* spec_of(void* select_state) { return (SpecState*)((char*)select_state + sizeof(SelState)); }
+static inline u64* spec_table_of(void* spec_buf) { return (u64*)spec_buf + SPEC_SLOTS * 8 + SPEC_CAP; }
+
+extern "C" int stein_spec_begin(void* hist, void* select_state, void* spec_buf, int64_t total, void* stream) {
+  if (!hist || !select_state || !spec_buf) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (total < 1) return fail(STEIN_E_SHAPE, "total < 1");
+  hipLaunchKernelGGL(k_median_init, dim3(16), dim3(256), 0, (hipStream_t)stream, (SelState*)select_state,
+                     spec_of(select_state), (u64)total, (u64*)hist, (u64*)spec_buf);
+  LAUNCH_CHECK("k_median_init");
+  return STEIN_OK;
+}
+
+extern "C" int stein_distance_block_spec(const void* theta_all, const float* r_all, int64_t n, int64_t d, int64_t row0,
+                                         int64_t n_local, int dtype, float* dist_out, int64_t ld_dist, void* hist_level0,
+                                         const void* x3_planes, int flags, void* select_state, void* spec_buf,
+                                         void* stream) {
+  if (!hist_level0 || !select_state || !spec_buf) return fail(STEIN_E_BADARG, "NULL pointer");
+  return distance_block_impl(theta_all, r_all, n, d, row0, n_local, dtype, dist_out, ld_dist, hist_level0, x3_planes,
+                             flags, stream, spec_of(select_state), (u64*)spec_buf);
+}
+
+extern "C" int stein_spec_tally(void* select_state, void* spec_buf, void* stream) {
+  if (!select_state || !spec_buf) return fail(STEIN_E_BADARG, "NULL pointer");
+  u64* table = spec_table_of(spec_buf);
+  HIP_TRY(hipMemsetAsync(table, 0, (size_t)SPEC_TABLE * 8, (hipStream_t)stream));
+  hipLaunchKernelGGL(k_spec_tally, dim3(256), dim3(256), 0, (hipStream_t)stream, spec_of(select_state),
+                     (const u64*)spec_buf, table);
+  LAUNCH_CHECK("k_spec_tally");
+  return STEIN_OK;
+}
+
+extern "C" int stein_spec_pick(void* select_state, void* spec_buf, int64_t n, float* h2_out, float* median_out,
+                               void* stream) {
+  if (!select_state || !spec_buf) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (n < 2) return fail(STEIN_E_BADARG, "n = %lld: need n >= 2", (long long)n);
+  hipLaunchKernelGGL(k_spec_pick, dim3(1), dim3(1024), 0, (hipStream_t)stream, (SelState*)select_state,
+                     spec_of(select_state), (const u64*)spec_table_of(spec_buf), (float)log((double)n), h2_out,
+                     median_out);
+  LAUNCH_CHECK("k_spec_pick");
+  return STEIN_OK;
+}
+
+extern "C" int stein_spec_update(void* select_state, void* stream) {
+  if (!select_state) return fail(STEIN_E_BADARG, "NULL pointer");
+  hipLaunchKernelGGL(k_spec_update, dim3(1), dim3(64), 0, (hipStream_t)stream, (const SelState*)select_state,
+                     spec_of(select_state));
+  LAUNCH_CHECK("k_spec_update");
+  return STEIN_OK;
 }
 
 extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n,

@@ -80,6 +80,23 @@ class HipStages:
         _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
                   _ptr(planes), _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
 
+    # -- speculative median window across ranks (include/steinhip.h) --
+    def spec_begin(self, hist, sel, spec, total):
+        _lib.call("stein_spec_begin", _ptr(hist), _ptr(sel), _ptr(spec), total, _stream(hist))
+
+    def distance_block_spec(self, T, r, n, d, row0, n_local, D, ld, hist0, sel, spec, planes=None):
+        _lib.call("stein_distance_block_spec", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
+                  _ptr(planes), 0, _ptr(sel), _ptr(spec), _stream(T))
+
+    def spec_tally(self, sel, spec):
+        _lib.call("stein_spec_tally", _ptr(sel), _ptr(spec), _stream(sel))
+
+    def spec_pick(self, sel, spec, n, h2, median):
+        _lib.call("stein_spec_pick", _ptr(sel), _ptr(spec), n, _ptr(h2), _ptr(median), _stream(sel))
+
+    def spec_update(self, sel):
+        _lib.call("stein_spec_update", _ptr(sel), _stream(sel))
+
     def median_begin(self, hist, sel, total):
         _lib.call("stein_median_begin", _ptr(hist), _ptr(sel), total, _stream(hist))
 
@@ -132,6 +149,11 @@ class SvgdEngine:
             x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
         self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
         self.flags = _lib.FLAG_X3 if self.x3 else 0
+        # several ranks: use the speculative median window (one 512 KB all-reduce and a hit-flag read-back per step
+        # instead of two passes over the local distance block) when the block is large enough for that to pay;
+        # STEIN_DIST_WINDOW=0/1 forces it
+        self.dist_window = False
+        self.window_hit = None
         self.device = torch.device(device)
         self.stages = stages if stages is not None else HipStages()
         self.group = group
@@ -156,6 +178,9 @@ class SvgdEngine:
         self.h2 = torch.zeros(1, dtype=torch.float32, device=dev)
         self.median = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+        if self.world > 1 and hasattr(self.stages, "spec_begin"):
+            env = os.environ.get("STEIN_DIST_WINDOW", "")
+            self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 28))
         if self.world > 1:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
@@ -187,7 +212,19 @@ class SvgdEngine:
 
     @property
     def select_state(self):
-        return self._section(_lib.WS_SELECT, 64, torch.uint8)
+        """radix-select state (64 bytes) followed by the speculative-window state (64 bytes)"""
+        return self._section(_lib.WS_SELECT, 128, torch.uint8)
+
+    @property
+    def spec_section(self):
+        o = self._offs[_lib.WS_SPEC]
+        return self.ws[o:self._offs[_lib.WS_PLANES]]
+
+    @property
+    def spec_table(self):
+        """the rank-summed window table (int64 view), behind the slots and the entry buffer of the SPEC section"""
+        o = self._offs[_lib.WS_SPEC] + 8 * _lib.SPEC_TABLE_OFFSET_WORDS
+        return self.ws[o:o + 8 * _lib.SPEC_TABLE_WORDS].view(torch.int64)
 
     @property
     def planes(self):
@@ -198,6 +235,41 @@ class SvgdEngine:
         return self.ws[o:self.ws_bytes]
 
     # ---------------------------------------------------------------------------------------
+    def _radix_levels(self, first_level, need_level0_pass=False):
+        """Levels first_level..2 of the radix select: local histogram pass (level 0 normally comes from the distance
+        epilogue), all-reduce over the ranks, resolve."""
+        st, n, nl, D, ld, hist, sel = self.stages, self.n, self.n_local, self.dist, self.ld_dist, self.hist, self.select_state
+        sym = self.world == 1
+        for level in range(first_level, _lib.HIST_LEVELS):
+            if level > 0 or need_level0_pass:
+                st.median_hist_pass(D, ld, nl, n, level, sel, hist, symmetric=sym)
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
+            st.median_resolve(hist, level, n, sel, self.h2, self.median)
+
+    def _median_with_window(self, T_all, mark):
+        """Several ranks, large blocks: the speculative window of the fused call, with the per-key tallies summed over
+        the ranks by one all-reduce.  The host reads the hit flag back (one small synchronising copy per step) to
+        decide whether the radix-select passes and their three all-reduces are needed at all."""
+        import torch.distributed as dist
+        st, n, d, nl = self.stages, self.n, self.d, self.n_local
+        D, ld, hist, sel, spec = self.dist, self.ld_dist, self.hist, self.select_state, self.spec_section
+        st.spec_begin(hist, sel, spec, n * n)
+        mark("distance")
+        st.distance_block_spec(T_all, self.rownorm, n, d, self.row0, nl, D, ld, hist[0], sel, spec, planes=self.planes)
+        mark("median")
+        st.spec_tally(sel, spec)
+        dist.all_reduce(self.spec_table, op=dist.ReduceOp.SUM, group=self.group)
+        st.spec_pick(sel, spec, n, self.h2, self.median)
+        flags = sel[_lib.SPEC_HIT_OFFSET:_lib.SPEC_SKIP_L0_OFFSET + 4].cpu()      # synchronises with the stream
+        hit = bool(flags[:4].view(torch.int32).item())
+        skip_l0 = bool(flags[-4:].view(torch.int32).item())
+        self.window_hit = hit
+        if not hit:
+            self._radix_levels(0, need_level0_pass=not skip_l0)
+        st.spec_update(sel)
+
     def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None, mark=None, timing=False):
         """theta_local, score_local: [n_local, d] float32 contiguous device tensors (this rank's rows).
 
@@ -241,16 +313,15 @@ class SvgdEngine:
         # the distance pass fills the level-0 histogram from its accumulators; a single rank holds the whole
         # symmetric matrix and only computes / counts its upper triangle
         sym = self.world == 1
-        st.median_begin(hist, sel, n * n)
-        mark("distance")
-        st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld, hist0=hist[0], symmetric=sym, planes=planes)
-        mark("median")
-        for level in range(_lib.HIST_LEVELS):
-            if level > 0:
-                st.median_hist_pass(D, ld, nl, n, level, sel, hist, symmetric=sym)
-            if self.world > 1:
-                dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
-            st.median_resolve(hist, level, n, sel, self.h2, self.median)
+        if self.dist_window:
+            self._median_with_window(T_all, mark)
+        else:
+            st.median_begin(hist, sel, n * n)
+            mark("distance")
+            st.distance_block(T_all, self.rownorm, n, d, self.row0, nl, D, ld, hist0=hist[0], symmetric=sym,
+                              planes=planes)
+            mark("median")
+            self._radix_levels(0)
         if K_out is not None:
             st.kernel_matrix(D, ld, nl, n, self.h2, K_out)
         mark("contract")
