@@ -182,6 +182,24 @@ __device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane
 //
 // The body is instantiated three times -- interior tile (no predicates), edge tile, diagonal tile -- and the
 // workgroup picks one with a single uniform branch.
+// LDS map of the distance epilogue (bytes from the start of the kernel's shared array)
+constexpr int EPI_STAGE_LD = 132;                             // floats per staged row: 128 columns + 4 pad
+constexpr int EPI_STAGE_BYTES = 64 * EPI_STAGE_LD * 4;        // 33792: half tile [64 rows][128 columns]
+constexpr int EPI_LDS_BYTES = EPI_STAGE_BYTES + 8192 + 64 + 8 * 1984 + 1024;   // + histogram, counters, queue, norms: 58944
+
+// the staged half tile (phase p: rows wy*64 + p*32 + 0..31 of the tile, staged as row wy*32 + r) -> D, 16 bytes per lane
+__device__ __forceinline__ void distance_store_rows(const float* __restrict__ stage, float* __restrict__ D, long ntc,
+                                                    int tile_m, int brow0, int p) {
+  const int t = threadIdx.x, f4 = t & 31;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int sr = (t >> 5) + 8 * k;
+    const int row = tile_m * BM + (sr >> 5) * 64 + p * 32 + (sr & 31);
+    *reinterpret_cast<float4*>(D + d_index(row, brow0 + 4 * f4, ntc)) =
+        *reinterpret_cast<const float4*>(stage + sr * EPI_STAGE_LD + 4 * f4);
+  }
+}
+
 struct SpecCtx {   // per-thread view of the speculative window (SPEC epilogues only)
   u32 lo, width;   // window [lo, lo + width] in key space
   u32* qcnt;       // LDS: entries pushed by this workgroup
@@ -193,15 +211,21 @@ template <bool MIRROR, bool PRED, bool DIAG, bool HIST, bool SPEC>
 __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
                                                        float* __restrict__ D, int n, int row0, int n_local, long ldD,
                                                        int tile_m, int brow0, u32 base, u64& packed, float two_s,
-                                                       SpecCtx& sx, const float* rr, const float* rc) {
+                                                       SpecCtx& sx, const float* rr, const float* rc, int i,
+                                                       float* __restrict__ stage) {
+  // One call handles acc[i][*]: rows wy*64 + i*32 .. +31 of the tile, the wave's 64 columns.
   // rr / rc: LDS copies of the tile's 128 row norms and 128 column norms (0 outside the matrix).  Read from global
   // memory here, the 66 dependent loads per thread were most of the epilogue's 35 k cycles.
+  // Interior tiles (no predicates) do not store D from here: every lane holds 4 consecutive ROWS of one column, so
+  // the tile would go out as 64 dword stores per thread, and store issue bounds the kernel (a non-symmetric row
+  // block wrote D at 1.6 TB/s).  They stage the half tile in LDS ([64 rows][EPI_STAGE_LD]) and
+  // distance_store_rows writes it with 16-byte stores along the rows.
+  constexpr bool STAGED = !PRED && !DIAG;
   const long ntc = ldD >> 5;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const int l31 = lane & 31, h4 = (lane >> 5) * 4;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = brow0 + wx * 64 + j * 32 + l31;
@@ -222,7 +246,8 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
           if (DIAG) w = lrow < col ? 2u : (lrow == col ? 1u : 0u);
           if (PRED && !(cok && rok)) w = 0u;
           if ((!PRED && !DIAG) || w) {
-            D[d_index(lrow, col, ntc)] = v[q];
+            if (STAGED) stage[(wy * 32 + 8 * g + h4 + q) * EPI_STAGE_LD + wx * 64 + j * 32 + l31] = v[q];
+            else D[d_index(lrow, col, ntc)] = v[q];
             if (DIAG && w == 2u) D[d_index(col, lrow, ntc)] = v[q];
             if (HIST) {
               const u32 dg = f32_key(v[q]) >> 21;
@@ -249,10 +274,11 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
   }
 }
 
-// `hl` is LDS that the caller no longer needs (all waves must be past their last LDS read): 8 KB histogram + 64 B +
-// 8 SPEC_QCAP B window queue + 1 KB row / column norms = 25152 B.  spec != NULL needs hist0 != NULL.
+// `lds` is the kernel's shared array, EPI_LDS_BYTES at least, which the caller no longer needs (all waves must be past
+// their last LDS read): half-tile staging, 8 KB histogram, counters, window queue, row / column norms.
+// spec != NULL needs hist0 != NULL.
 template <bool SYM>
-__device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
+__device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* lds, const float* __restrict__ r,
                                                   float* __restrict__ D, int n, int row0, int n_local, long ldD,
                                                   int tile_m, int tile_n, u64* __restrict__ hist0,
                                                   float two_s = 2.f, SpecState* __restrict__ spec = nullptr,
@@ -262,6 +288,8 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const int brow0 = tile_n * BN;
+  float* stage = reinterpret_cast<float*>(lds);
+  u32* hl = lds + EPI_STAGE_BYTES / 4;
   u64 packed = 0ull;
   u32 base = 0u;
   SpecCtx sx;
@@ -295,22 +323,35 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   }
   const bool diag = SYM && tile_m == tile_n;
   const bool edge = brow0 + BN > n || tile_m * BM + BM > n_local;
-#define STEIN_EPI(MIRROR, PRED, DIAG)                                                                                  \
+#define STEIN_EPI_I(MIRROR, PRED, DIAG, I)                                                                             \
   do {                                                                                                                 \
     if (window)                                                                                                        \
       distance_epilogue_body<MIRROR, PRED, DIAG, false, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
-                                                              base, packed, two_s, sx, rr, rc);                       \
+                                                              base, packed, two_s, sx, rr, rc, I, stage);             \
     else if (hist)                                                                                                     \
       distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
-                                                              base, packed, two_s, sx, rr, rc);                       \
+                                                              base, packed, two_s, sx, rr, rc, I, stage);             \
     else                                                                                                               \
       distance_epilogue_body<MIRROR, PRED, DIAG, false, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,   \
-                                                               base, packed, two_s, sx, rr, rc);                      \
+                                                               base, packed, two_s, sx, rr, rc, I, stage);            \
   } while (0)
-  if (diag) STEIN_EPI(false, true, true);
-  else if (edge) STEIN_EPI(SYM, true, false);
-  else STEIN_EPI(SYM, false, false);
-#undef STEIN_EPI
+  const long ntc = ldD >> 5;
+  if (diag) {
+    STEIN_EPI_I(false, true, true, 0);
+    STEIN_EPI_I(false, true, true, 1);
+  } else if (edge) {
+    STEIN_EPI_I(SYM, true, false, 0);
+    STEIN_EPI_I(SYM, true, false, 1);
+  } else {   // interior: the two row halves go through the LDS staging
+    STEIN_EPI_I(SYM, false, false, 0);
+    __syncthreads();
+    distance_store_rows(stage, D, ntc, tile_m, brow0, 0);
+    __syncthreads();
+    STEIN_EPI_I(SYM, false, false, 1);
+    __syncthreads();
+    distance_store_rows(stage, D, ntc, tile_m, brow0, 1);
+  }
+#undef STEIN_EPI_I
   if (hist) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

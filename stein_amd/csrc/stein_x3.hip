@@ -382,7 +382,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
                                                              int row0, int n_local, long ldD, int tiles_m, int tiles_n,
                                                              u64* __restrict__ hist0, const float* __restrict__ two_s,
                                                              SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XOPER];
+  // two operand tiles in the main loop; the epilogue reuses the array (EPI_LDS_BYTES)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XOPER > EPI_LDS_BYTES ? 2 * XOPER : EPI_LDS_BYTES];
   unsigned char* As = smem;
   unsigned char* Bs = smem + XOPER;
   int tile_m, tile_n;

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
                                                        float* __restrict__ D, int n, int d, int row0, int n_local,
                                                        long ldD, int tiles_m, int tiles_n, u64* __restrict__ hist0,
                                                        SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  constexpr int kStage = (BM + BN) * LDK, kEpi = EPI_LDS_BYTES / 4;   // main loop tiles; the epilogue reuses the array
+  __shared__ __attribute__((aligned(16))) float smem[kStage > kEpi ? kStage : kEpi];
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
