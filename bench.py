@@ -282,7 +282,7 @@ def main():
         free = torch.cuda.mem_get_info(device)[0]
         if need < free * 0.9:
             torch.cuda.empty_cache()
-            r2 = run_workload(torch, dist, args, wl2, device, rank, world, group, args.secondary_steps, 1)
+            r2 = run_workload(torch, dist, args, wl2, device, rank, world, group, args.secondary_steps, 3)   # 3 warm-up steps: the median predictor needs two medians of history
             k2 = r2["stages"].get("contract")
             f2 = 4.0 * r2["n_local"] * r2["n"] * r2["d"]
             out["secondary"] = {
