@@ -249,7 +249,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["name"], "n": n, "d": d, "rows_per_rank": nl,
                    "optimizer": "adagrad lr=1e-3 alpha=0.9",
-                   "parallelism": "rows sharded x%d, all-gather(theta,G)+3 hist all-reduce+1 scalar all-reduce" % world
+                   "parallelism": "rows sharded x%d, all-gather(theta,G) + median (3 histogram all-reduces, or one window-table "
+                                  "all-reduce when the local block has >= 2^28 entries) + 1 scalar all-reduce" % world
                    if world > 1 else "single GPU"},
         "element_updates_per_s": value * d,
         "pair_interactions_per_s": value * n,

@@ -434,6 +434,9 @@ __global__ __launch_bounds__(1024) void k_spec_pick(SelState* st, SpecState* sp,
   __shared__ u32 found[2];
   const int t = threadIdx.x;
   const u32 width = sp->width, lo = sp->lo_key;
+  // k_spec_update sizes the next window from `count`: make it the GLOBAL number of entries so that every rank's
+  // predictor stays identical (the local counts differ from rank to rank)
+  if (t == 0) sp->count = table[2] > 0xffffffffull ? 0xffffffffu : (u32)table[2];
   if (width == 0u || table[1] != 0ull) return;   // miss on every rank alike
   const u64 total = sp->total, below = table[0];
   const u64 r0 = (total & 1ull) ? total / 2 : total / 2 - 1, r1 = total / 2;
