@@ -127,7 +127,7 @@ struct SpecState {
 };
 static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;
-constexpr u32 SPEC_QCAP = 1984;          // per-workgroup LDS queue (entries of 8 bytes)
+constexpr u32 SPEC_QCAP = 1016;          // per-workgroup LDS queue (entries of 8 bytes; shares its LDS with the histogram)
 constexpr u32 SPEC_CAP = (1u << 21) - 2048u;   // global buffer capacity (entries); the 16 MB section starts with
 constexpr u32 SPEC_SLOTS = 256;                 // 256 "below" counters, one per 64-byte line (8 u64 apart): every
                                                 // workgroup adding to ONE address serialised at the L2 (+165 us)
@@ -185,7 +185,7 @@ __device__ __forceinline__ void hist_add(u32* h, u32 digit, bool valid, int lane
 // LDS map of the distance epilogue (bytes from the start of the kernel's shared array)
 constexpr int EPI_STAGE_LD = 132;                             // floats per staged row: 128 columns + 4 pad
 constexpr int EPI_STAGE_BYTES = 64 * EPI_STAGE_LD * 4;        // 33792: half tile [64 rows][128 columns]
-constexpr int EPI_LDS_BYTES = EPI_STAGE_BYTES + 8192 + 64 + 8 * 1984 + 1024;   // + histogram, counters, queue, norms: 58944
+constexpr int EPI_LDS_BYTES = EPI_STAGE_BYTES + 8192 + 64 + 1024;   // + histogram OR window queue, counters, norms: 43072
 
 // the staged half tile (phase p: rows wy*64 + p*32 + 0..31 of the tile, staged as row wy*32 + r) -> D, 16 bytes per lane
 __device__ __forceinline__ void distance_store_rows(const float* __restrict__ stage, float* __restrict__ D, long ntc,
@@ -295,8 +295,9 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   SpecCtx sx;
   sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u;
   sx.qcnt = hl + STEIN_HIST_BINS;                               // 16 u32 reserved
-  sx.q = reinterpret_cast<u64*>(hl + STEIN_HIST_BINS + 16);
-  float* rr = reinterpret_cast<float*>(hl + STEIN_HIST_BINS + 16 + 2 * SPEC_QCAP);   // [128] row norms, [128] column norms
+  sx.q = reinterpret_cast<u64*>(hl);                            // a step has a window (queue) or a histogram, never both
+  static_assert(8 * SPEC_QCAP <= 4 * STEIN_HIST_BINS, "the window queue lives in the histogram's LDS");
+  float* rr = reinterpret_cast<float*>(hl + STEIN_HIST_BINS + 16);   // [128] row norms, [128] column norms
   float* rc = rr + BM;
   {
     const int idx = t < BM ? tile_m * BM + t : brow0 + (t - BM);

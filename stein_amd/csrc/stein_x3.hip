@@ -377,15 +377,16 @@ __device__ __forceinline__ void x3_mma_tile(const unsigned char* As, const unsig
 }
 
 template <bool SYM, int NP>
-__global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restrict__ T3, int ntk,
+__global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restrict__ T3, int ntk,
                                                              const float* __restrict__ r, float* __restrict__ D, int n,
                                                              int row0, int n_local, long ldD, int tiles_m, int tiles_n,
                                                              u64* __restrict__ hist0, const float* __restrict__ two_s,
                                                              SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
   // two operand tiles in the main loop; the epilogue reuses the array (EPI_LDS_BYTES)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XOPER > EPI_LDS_BYTES ? 2 * XOPER : EPI_LDS_BYTES];
+  constexpr int OP = NP * XPLANE;   // one operand tile: NP planes
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP > EPI_LDS_BYTES ? 2 * OP : EPI_LDS_BYTES];
   unsigned char* As = smem;
-  unsigned char* Bs = smem + XOPER;
+  unsigned char* Bs = smem + OP;
   int tile_m, tile_n;
   if (!distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n)) return;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -404,49 +405,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance_x3(const u16* __restri
   const u16* __restrict__ pa1 = t3_chunk_ptr(T3, ntk, arow0 + (t >> 2) + 64, t & 3);
   const u16* __restrict__ pb0 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2), t & 3);
   const u16* __restrict__ pb1 = t3_chunk_ptr(T3, ntk, brow0 + (t >> 2) + 64, t & 3);
-  // two register sets (X: even k tiles, Y: odd): a tile's loads are issued two tiles ahead, as soon as its set has been
-  // copied to LDS, so they have two MFMA phases to arrive (one phase was shorter than the L2 latency under load:
-  // 8 k cycles of every 22 k-cycle main loop went to waiting for them)
-  u32x4 raX[6], rbX[6], raY[6], rbY[6];
+  // the next k tile's operands are prefetched into registers under the MFMAs (a second register set, two tiles
+  // ahead, bought nothing and costs the third workgroup per CU)
+  u32x4 ra[6], rb[6];
 #ifdef STEIN_STAMPS
   u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
   u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
-  t3_load<NP>(pa0, pa1, 0, raX);
-  t3_load<NP>(pb0, pb1, 0, rbX);
-  if (ntk > 1) {
-    t3_load<NP>(pa0, pa1, 1, raY);
-    t3_load<NP>(pb0, pb1, 1, rbY);
-  }
-  for (int kt = 0; kt < ntk; kt += 2) {
-    x3_store_swz<NP>(As, t, raX);
-    x3_store_swz<NP>(Bs, t, rbX);
+  t3_load<NP>(pa0, pa1, 0, ra);
+  t3_load<NP>(pb0, pb1, 0, rb);
+  for (int kt = 0; kt < ntk; ++kt) {
+    x3_store_swz<NP>(As, t, ra);
+    x3_store_swz<NP>(Bs, t, rb);
     STAMP(0);   // waiting for the tile's loads + LDS stores
     __syncthreads();
     STAMP(1);   // barrier
-    if (kt + 2 < ntk) {
-      t3_load<NP>(pa0, pa1, kt + 2, raX);
-      t3_load<NP>(pb0, pb1, kt + 2, rbX);
+    if (kt + 1 < ntk) {
+      t3_load<NP>(pa0, pa1, kt + 1, ra);
+      t3_load<NP>(pb0, pb1, kt + 1, rb);
     }
     x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
     STAMP(2);   // load issue + fragment reads + MFMAs
     __syncthreads();
     STAMP(1);
-    if (kt + 1 < ntk) {
-      x3_store_swz<NP>(As, t, raY);
-      x3_store_swz<NP>(Bs, t, rbY);
-      STAMP(0);
-      __syncthreads();
-      STAMP(1);
-      if (kt + 3 < ntk) {
-        t3_load<NP>(pa0, pa1, kt + 3, raY);
-        t3_load<NP>(pb0, pb1, kt + 3, rbY);
-      }
-      x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
-      STAMP(2);
-      __syncthreads();
-      STAMP(1);
-    }
   }
   distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, *two_s,
                          spec, spec_buf);
