@@ -158,7 +158,9 @@ int stein_spec_update(void* select_state, void* stream);
  * selects the 16-bit-MFMA kernels there; NULL selects the fp32-MFMA kernels.
  * dtype = STEIN_BF16 (BASELINE config 2): theta_all / score_all hold bf16 values; they are the single operand plane,
  * K is rounded to bf16 once (its rowsum uses the rounded values), every product is one bf16 MFMA with fp32
- * accumulation.  bf16 inputs always need STEIN_FLAG_X3 / the planes. */
+ * accumulation.  bf16 inputs always need STEIN_FLAG_X3 / the planes.
+ * Either matrix may be NULL: then only the other one's scales and planes are rebuilt (theta before the distance pass,
+ * the score any time before the contraction -- e.g. while its all-gather overlaps the distance pass). */
 int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, int dtype, void* x3_planes,
                      size_t planes_bytes, void* stream);
 

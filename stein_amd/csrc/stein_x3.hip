@@ -165,9 +165,10 @@ __device__ __forceinline__ int scale_exp(u32 maxbits, int lim) {
 // blockIdx.z = 0: X0 -> cmax[0, dc), 1: X1 -> cmax[dc, 2 dc)
 template <typename TIN>
 __global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
-                                                u32* __restrict__ cmax0, int dc) {
-  const TIN* __restrict__ X = blockIdx.z ? X1 : X0;
-  u32* __restrict__ cmax = cmax0 + (blockIdx.z ? dc : 0);
+                                                u32* __restrict__ cmax0, int dc, int zbase) {
+  const int z = blockIdx.z + zbase;
+  const TIN* __restrict__ X = z ? X1 : X0;
+  u32* __restrict__ cmax = cmax0 + (z ? dc : 0);
   __shared__ u32 red[4][64];
   const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
   const int col = blockIdx.x * 64 + cx;
@@ -221,8 +222,9 @@ __device__ __forceinline__ float load_as_f32(const u16* p) { return __uint_as_fl
 template <typename TIN, int KIND>
 __global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
                                                u16* __restrict__ R0, long r_rows, int dk, u16* __restrict__ Tt0,
-                                               u16* __restrict__ Tt1, int dc, long nk, const float* __restrict__ sc) {
-  const bool score = blockIdx.z != 0;
+                                               u16* __restrict__ Tt1, int dc, long nk, const float* __restrict__ sc,
+                                               int zbase) {
+  const bool score = blockIdx.z + zbase != 0;
   if (score && (blockIdx.x * 64 >= dc || (long)blockIdx.y * 64 >= nk)) return;
   const TIN* __restrict__ X = score ? X1 : X0;
   u16* __restrict__ R = score ? nullptr : R0;
@@ -702,11 +704,14 @@ int stein_x3_kind(int dtype) { return split_kind(dtype); }
 template <typename TIN, int KIND>
 static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score, int64_t n, int64_t d,
                          const SteinLayout& L, u16* T3, u16* Tt3, u16* Gt3, const float* sc) {
+  // grid.z walks [theta, score]; a NULL matrix is left out (its planes keep their contents)
+  const unsigned nz = (theta ? 1u : 0u) + (score ? 1u : 0u);
+  const int zbase = theta ? 0 : 1;
   const int64_t rows = L.x3_rows > L.x3_nk ? L.x3_rows : L.x3_nk;   // particle extent to cover (both multiples of 32)
   const int64_t cols = L.x3_dk > L.x3_dc ? L.x3_dk : L.x3_dc;      // parameter extent
-  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), 2u);
+  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), nz);
   hipLaunchKernelGGL((k_split<TIN, KIND>), grid, dim3(256), 0, stream, theta, score, (int)n, (int)d, T3,
-                     (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc);
+                     (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc, zbase);
 }
 
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
@@ -718,13 +723,15 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
   const int dc = (int)L.x3_dc;
   u32* cmax = reinterpret_cast<u32*>(sc + 4 * dc + 4);
   const int kind = split_kind(dtype);
-  if (kind == 2) {
-    HIP_TRY(hipMemsetAsync(cmax, 0, (size_t)2 * dc * sizeof(u32), stream));
+  if (kind == 2) {   // column maxima of the matrices given (cmax = [score | theta]); the other half keeps its values
+    const int zbase = score_all ? 0 : 1;
+    const unsigned nz = (score_all ? 1u : 0u) + (theta_all ? 1u : 0u);
+    HIP_TRY(hipMemsetAsync(cmax + (size_t)zbase * dc, 0, (size_t)nz * dc * sizeof(u32), stream));
     int gy = (int)((n + 63) / 64);
     if (gy > 256) gy = 256;
-    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, 2u);
+    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, nz);
     hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (const float*)theta_all,
-                       (int)n, (int)d, cmax, dc);
+                       (int)n, (int)d, cmax, dc, zbase);
     LAUNCH_CHECK("k_colmax");
   }
   hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(256), 0, stream, cmax, dc, sc, kind == 2 ? PEXP_H2 : 0,

@@ -853,7 +853,7 @@ extern "C" int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int
 
 extern "C" int stein_x3_prepare(const void* theta_all, const void* score_all, int64_t n, int64_t d, int dtype,
                                 void* x3_planes, size_t planes_bytes, void* stream) {
-  if (!theta_all || !score_all || !x3_planes) return fail(STEIN_E_BADARG, "NULL pointer");
+  if ((!theta_all && !score_all) || !x3_planes) return fail(STEIN_E_BADARG, "NULL pointer");
   SteinLayout L;
   int rc = stein_make_layout(n, n, d, dtype, STEIN_FLAG_X3, &L);
   if (rc) return rc;

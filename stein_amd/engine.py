@@ -71,7 +71,9 @@ class HipStages:
                   _ptr(K), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
     def x3_prepare(self, T, G, n, d, planes):
-        _lib.call("stein_x3_prepare", _ptr(T), _ptr(G), n, d, _dt(T), _ptr(planes), planes.numel(), _stream(T))
+        """T or G may be None: only the other matrix's scales and planes are rebuilt."""
+        ref = T if T is not None else G
+        _lib.call("stein_x3_prepare", _ptr(T), _ptr(G), n, d, _dt(ref), _ptr(planes), planes.numel(), _stream(ref))
 
     def rownorms(self, T, n, d, r):
         _lib.call("stein_rownorms", _ptr(T), n, d, _dt(T), _ptr(r), _stream(T))
@@ -296,11 +298,13 @@ class SvgdEngine:
             def mark(label):
                 return None
 
+        gather_g = None
         if self.world > 1:
             import torch.distributed as dist
             mark("gather")
+            # the score rows are not needed before the contraction: their all-gather runs beside the distance pass
+            gather_g = dist.all_gather_into_tensor(self.G_all, score_local, group=self.group, async_op=True)
             dist.all_gather_into_tensor(self.T_all, theta_local, group=self.group)
-            dist.all_gather_into_tensor(self.G_all, score_local, group=self.group)
             T_all, G_all = self.T_all, self.G_all
         else:
             T_all, G_all = theta_local, score_local
@@ -309,7 +313,7 @@ class SvgdEngine:
         st.rownorms(T_all, n, d, self.rownorm)
         planes = self.planes
         if planes is not None:
-            st.x3_prepare(T_all, G_all, n, d, planes)
+            st.x3_prepare(T_all, None if gather_g is not None else G_all, n, d, planes)
         # the distance pass fills the level-0 histogram from its accumulators; a single rank holds the whole
         # symmetric matrix and only computes / counts its upper triangle
         sym = self.world == 1
@@ -324,6 +328,10 @@ class SvgdEngine:
             self._radix_levels(0)
         if K_out is not None:
             st.kernel_matrix(D, ld, nl, n, self.h2, K_out)
+        if gather_g is not None:
+            gather_g.wait()            # the launching stream waits for the gathered score rows (the host does not)
+            if planes is not None:
+                st.x3_prepare(None, G_all, n, d, planes)
         mark("contract")
         st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws, planes)
         mark("finish")
