@@ -31,18 +31,20 @@ def _staged(eng, T, G):
     return eng.compute_phi(T, G, mark=lambda label: None)
 
 
-@pytest.mark.parametrize("n,d,x3", [(2048, 32, True), (1001, 17, True), (1536, 64, False)])
-def test_window_hits_and_matches_radix_select(cuda, n, d, x3):
+@pytest.mark.parametrize("n,d,x3,dtype", [(2048, 32, True, torch.float32), (1001, 17, True, torch.float32),
+                                          (1536, 64, False, torch.float32), (1280, 48, True, torch.bfloat16)])
+def test_window_hits_and_matches_radix_select(cuda, n, d, x3, dtype):
     g = torch.Generator(device="cpu").manual_seed(n + d)
     T = torch.randn(n, d, generator=g).to(cuda)
-    G = torch.randn(n, d, generator=g).to(cuda)
-    V = 1e-3 * torch.randn(n, d, generator=g).to(cuda)          # a steady drift, like a small optimizer step
-    fused, ref = SvgdEngine(n, d, device=cuda, x3=x3), SvgdEngine(n, d, device=cuda, x3=x3)
+    G = torch.randn(n, d, generator=g).to(cuda).to(dtype)
+    V = (1e-3 if dtype == torch.float32 else 2e-2) * torch.randn(n, d, generator=g).to(cuda)   # a steady drift
+    fused, ref = SvgdEngine(n, d, device=cuda, x3=x3, dtype=dtype), SvgdEngine(n, d, device=cuda, x3=x3, dtype=dtype)
     hits = []
     for step in range(10):
-        phi = fused.compute_phi(T, G).clone()
+        Tq = T.to(dtype)
+        phi = fused.compute_phi(Tq, G).clone()
         h2 = fused.h2.clone()
-        phi_ref = _staged(ref, T, G)
+        phi_ref = _staged(ref, Tq, G)
         torch.cuda.synchronize()
         assert torch.equal(h2, ref.h2), "step %d: h2 %r vs %r (%r)" % (step, float(h2), float(ref.h2), _spec_state(fused))
         assert torch.equal(phi, phi_ref)
