@@ -5,8 +5,9 @@ Two uses:
   * tests/test_radix_model.py checks the radix-select algorithm itself (key transform, two-target tracking,
     even/odd handling) against np.partition, on CPU;
   * tests/test_distributed_cpu.py plugs `NumpyStages` into stein_amd.engine.SvgdEngine in place of the HIP
-    backend so the multi-rank collective protocol (all-gather of rows, histogram all-reduce, |phi|^2
-    all-reduce, identical bandwidth on every rank) runs under gloo with world_size 2 on CPU.
+    backend so the multi-rank collective protocol (all-gather of rows, histogram all-reduce or window-table
+    all-reduce with the hit read-back, |phi|^2 all-reduce, identical bandwidth on every rank) runs under gloo
+    with world_size 2 on CPU.
 
 It mirrors the semantics of the C ABI in include/steinhip.h, not its performance structure.
 """
@@ -65,6 +66,7 @@ def resolve(hist, level, n, st):
     st.diverged = st.prefix[0] != st.prefix[1]
     if level == LEVELS - 1:
         lo, hi = key_to_f32(st.prefix[0]), key_to_f32(st.prefix[1])
+        st.lo, st.hi = lo, hi
         st.median = np.float32(0.5) * (lo + hi) if st.even else lo
         with np.errstate(invalid="ignore", divide="ignore"):
             st.h2 = orc.bandwidth_sq(st.median, n, np.float32) if n >= 2 else None
@@ -111,6 +113,91 @@ class NumpyStages:
     def median_begin(self, hist, sel, total):
         hist.zero_()
         self._st = SelectState(total)
+
+    # ---- speculative window across ranks (stein_common.h: SpecState; steinhip.hip: k_median_init, k_spec_tally,
+    #      k_spec_pick, k_spec_update).  The predictor lives in self._sp; the two state words the engine reads back
+    #      (hit, skip_l0) are mirrored into the SELECT section at the offsets of the device struct. ----
+    HW_MAX, TABLE_HDR, TABLE_OFF = 32767, 8, 1 << 21
+
+    def _flags(self, sel):
+        u = sel.numpy().view(np.uint32)
+        u[(64 + 28) // 4] = 1 if self._sp["hit"] else 0
+        u[(64 + 52) // 4] = 1 if self._sp["skip_l0"] else 0
+
+    def spec_begin(self, hist, sel, spec, total):
+        hist.zero_()
+        self._st = SelectState(total)
+        sp = getattr(self, "_sp", None) or dict(magic=0, center=0, halfwidth=0, last_key=0)
+        ok = sp["magic"] in (1, 2) and sp["halfwidth"] <= self.HW_MAX and sp["halfwidth"] <= sp["center"] <= 0xFFFFFFFE - sp["halfwidth"]
+        sp.update(lo=sp["center"] - sp["halfwidth"] if ok else 0xFFFFFFFF, width=2 * sp["halfwidth"] if ok else 0,
+                  count=0, hit=False, below=0, total=total, entries=np.zeros(0, dtype=np.int64))
+        sp["skip_l0"] = sp["width"] == 0
+        self._sp = sp
+        self._flags(sel)
+
+    def distance_block_spec(self, T, r, n, d, row0, n_local, D, ld, hist0, sel, spec, planes=None):
+        sp = self._sp
+        if sp["width"] == 0:     # no window: the level-0 histogram comes from the distance pass, as without the window
+            return self.distance_block(T, r, n, d, row0, n_local, D, ld, hist0=hist0)
+        self.distance_block(T, r, n, d, row0, n_local, D, ld, hist0=None)
+        keys = f32_keys(D.numpy()[:n_local, :n]).reshape(-1).astype(np.int64)
+        sp["below"] = int((keys < sp["lo"]).sum())
+        inside = keys[(keys >= sp["lo"]) & (keys <= sp["lo"] + sp["width"])]
+        sp["entries"], sp["count"] = inside - sp["lo"], int(inside.size)
+
+    def _table(self, spec):
+        return spec.numpy().view(np.int64)[self.TABLE_OFF:self.TABLE_OFF + self.TABLE_HDR + 2 * self.HW_MAX + 2]
+
+    def spec_tally(self, sel, spec):
+        sp, table = self._sp, self._table(spec)
+        table[:] = 0
+        table[0], table[2] = sp["below"], sp["count"]
+        if sp["width"] == 0:
+            table[1] = 1
+        else:
+            np.add.at(table[self.TABLE_HDR:], sp["entries"], 1)
+
+    def spec_pick(self, sel, spec, n, h2, median):
+        sp, st, table = self._sp, self._st, self._table(spec)
+        sp["count"] = int(table[2])                         # the GLOBAL count sizes the next window on every rank alike
+        if sp["width"] == 0 or table[1] != 0:
+            return
+        total, below = sp["total"], int(table[0])
+        r0 = total // 2 if total % 2 else total // 2 - 1
+        r1 = total // 2
+        cum = np.cumsum(table[self.TABLE_HDR:self.TABLE_HDR + sp["width"] + 1])
+        if r0 < below or r1 - below >= cum[-1]:
+            return
+        k0 = int(np.searchsorted(cum, r0 - below, side="right"))
+        k1 = int(np.searchsorted(cum, r1 - below, side="right"))
+        lo, hi = key_to_f32(sp["lo"] + k0), key_to_f32(sp["lo"] + k1)
+        st.lo, st.hi = lo, hi
+        st.median = np.float32(0.5) * (lo + hi) if st.even else lo
+        st.h2 = orc.bandwidth_sq(st.median, n, np.float32)
+        h2.numpy()[0], median.numpy()[0] = st.h2, st.median
+        sp["hit"] = sp["skip_l0"] = True
+        self._flags(sel)
+
+    def spec_update(self, sel):
+        sp, st = self._sp, self._st
+        lo = getattr(st, "lo", None)
+        if lo is None:                                       # the radix passes produced the median: its lower target
+            lo = key_to_f32(st.prefix[0])
+        key = int(f32_keys(np.float32(lo)).reshape(-1)[0])
+        hw, nxt = 4096, key
+        if sp["magic"] in (1, 2):
+            pred = np.float32(2) * np.float32(lo) - key_to_f32(sp["last_key"])
+            c = int(f32_keys(pred if pred == pred else np.float32(lo)).reshape(-1)[0])
+            nxt = min(max(c, 65536), 0xFFFE0000)
+            if sp["magic"] == 2 and sp["width"] != 0:
+                err = abs(key - sp["center"])
+                hw = self.HW_MAX if err > self.HW_MAX // 4 else 4 * err + 48
+                if sp["hit"] and sp["count"] > ((1 << 21) - 2048) // 2 and hw > sp["halfwidth"] // 2:
+                    hw = sp["halfwidth"] // 2 + 1
+            sp["magic"] = 2
+        else:
+            sp["magic"] = 1
+        sp.update(last_key=key, center=nxt, halfwidth=min(hw, self.HW_MAX))
 
     def median_hist_pass(self, D, ld, n_local, n, level, sel, hist, symmetric=False):
         hist_pass(D.numpy()[:n_local, :n], level, self._st, hist.numpy()[level])

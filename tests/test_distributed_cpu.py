@@ -72,6 +72,54 @@ def test_two_rank_protocol_matches_single_rank(tmp_path, n, d):
     np.testing.assert_allclose(parts[0]["sqnorm"][0], ref["sqnorm"], rtol=1e-5)
 
 
+def _worker_window(rank, world, port, n, d, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["STEIN_DIST_WINDOW"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stein_amd import _lib
+        from stein_amd.engine import SvgdEngine
+        from oracle.staged_model import NumpyStages
+        rng = np.random.default_rng(5)
+        T, G, V = rng.normal(size=(n, d)), rng.normal(size=(n, d)), 1e-3 * rng.normal(size=(n, d))
+        eng = SvgdEngine(n, d, device="cpu", group=dist.group.WORLD, stages=NumpyStages(_lib.workspace_layout))
+        assert eng.dist_window
+        sl = slice(eng.row0, eng.row0 + eng.n_local)
+        sc = torch.tensor(G[sl], dtype=torch.float32).contiguous()
+        h2s, hits = [], []
+        for step in range(steps):
+            if step == steps - 2:
+                T = T * 2.0                                   # a jump: the window misses, the radix protocol takes over
+            th = torch.tensor((T + step * V)[sl], dtype=torch.float32).contiguous()
+            eng.compute_phi(th, sc)
+            h2s.append(float(eng.h2[0]))
+            hits.append(int(eng.window_hit))
+        np.savez(os.path.join(out_dir, "win%d.npz" % rank), h2=h2s, hits=hits)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_window_protocol(tmp_path):
+    """The engine's window protocol (tally, table all-reduce, pick, hit read-back, fall-back to the radix
+    protocol) with the NumPy stage model: the bandwidth of every step equals the oracle's, on both ranks."""
+    world, n, d, steps = 2, 96, 5, 8
+    mp.spawn(_worker_window, args=(world, _free_port(), n, d, steps, str(tmp_path)), nprocs=world, join=True)
+    from oracle import svgd_oracle as orc
+    rng = np.random.default_rng(5)
+    T, G, V = rng.normal(size=(n, d)), rng.normal(size=(n, d)), 1e-3 * rng.normal(size=(n, d))
+    parts = [np.load(os.path.join(str(tmp_path), "win%d.npz" % r)) for r in range(world)]
+    for step in range(steps):
+        if step == steps - 2:
+            T = T * 2.0
+        T32 = (T + step * V).astype(np.float32).astype(np.float64)
+        ref = orc.svgd_step(T32, G.astype(np.float32).astype(np.float64), orc.AdagradState(), np.float32)
+        assert parts[0]["h2"][step] == parts[1]["h2"][step] == ref["h2"], step
+    hits = list(parts[0]["hits"])
+    assert hits == list(parts[1]["hits"])
+    assert hits[0] == 0 and sum(hits[2:steps - 2]) >= 2 and hits[steps - 2] == 0, hits
+
+
 def test_uneven_sharding_is_refused():
     from stein_amd import _lib
     from stein_amd.engine import SvgdEngine
