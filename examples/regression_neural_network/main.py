@@ -3,7 +3,7 @@ examples/regression_neural_network/main.py: one hidden layer of 100 ReLU units o
 Gamma(1, 0.01) priors on the weight precision lambda and the noise precision gamma (both sampled in log space),
 20 particles, Adam(0.1, decay 0.999).  d = 3 H + 3 = 303 parameters per particle.
 
-    python examples/regression_neural_network/main.py [--particles 20] [--iters 3000]
+    python examples/regression_neural_network/main.py [--particles 20] [--iters 3000] [--autograd]
 """
 import argparse
 import math
@@ -16,6 +16,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from stein_amd.optimizers import AdamGradientDescent  # noqa: E402
 from stein_amd.samplers import SteinSampler  # noqa: E402
+from stein_amd.scores import BnnScore  # noqa: E402
 
 H = 100
 
@@ -52,6 +53,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--particles", type=int, default=20)
     ap.add_argument("--iters", type=int, default=1500)
+    ap.add_argument("--autograd", action="store_true", help="differentiate log_posterior with torch instead of the HIP score producer")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     X = rng.uniform(size=(20, 1))
@@ -69,6 +71,8 @@ def main():
     sampler = SteinSampler(args.particles, make_log_posterior(len(X), len(X)),
                            AdamGradientDescent(learning_rate=5e-2, decay=0.999), theta=init, model_vars=shapes)
     assert sampler.n_params == 3 * H + 3
+    if not args.autograd:   # closed-form backprop of the same log posterior in one HIP launch (stein_amd/scores.py)
+        sampler.score = BnnScore(1, H, BnnScore.columns(sampler._access), n_train=len(X))
     for i in range(args.iters):
         sampler.train_on_batch(feed)
         if i % 250 == 0 or i == args.iters - 1:

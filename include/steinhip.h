@@ -259,6 +259,16 @@ int stein_score_glm(const float* theta, int64_t n, int64_t d, int kind, int64_t 
                     const float* X, const float* y, int64_t batch, double scale, double prior_precision,
                     double gamma_rate, float* score, void* stream);
 
+/* Bayesian neural-network regression with one hidden ReLU layer, examples/regression_neural_network/main.py:29-85:
+ *   pred = relu(X w1 + b1) w2 + b2;  log p = [ (n_train / batch) sum_b log N(y_b; pred_b, 1/gamma) + log Gamma(lambda; a, b)
+ *   + log Gamma(gamma; a, b) + sum over all weights of log N(.; 0, 1/lambda) ] / n_train, lambda = exp(log_lambda),
+ *   gamma = exp(log_gamma), densities evaluated without a Jacobian term, as the reference does.
+ *   cols[6]: first column of w1 ([n_in][n_hidden] row-major), b1 [n_hidden], w2 [n_hidden], b2, log_lambda, log_gamma in
+ *   the packed particle; any other column gets score 0.  n_in <= 4, n_hidden <= 1024. */
+int stein_score_bnn(const float* theta, int64_t n, int64_t d, int64_t n_in, int64_t n_hidden, const int64_t* cols,
+                    const float* X, const float* y, int64_t batch, double n_train, double gamma_a, double gamma_b,
+                    float* score, void* stream);
+
 /* small helpers used by the host layer */
 int stein_cast_f64_to_f32(const double* src, float* dst, int64_t count, void* stream);
 int stein_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "stein_spec_pick": [_vp, _vp, _i64, _vp, _vp, _vp],
     "stein_spec_update": [_vp, _vp],
     "stein_score_glm": [_vp, _i64, _i64, _int, _i64, _i64, _i64, _vp, _vp, _i64, _dbl, _dbl, _dbl, _vp, _vp],
+    "stein_score_bnn": [_vp, _i64, _i64, _i64, _i64, _c.POINTER(_i64), _vp, _vp, _i64, _dbl, _dbl, _dbl, _vp, _vp],
     "stein_timing_reserve": [_int],
     "stein_timing_read": [_c.POINTER(_c.c_float), _int, _c.POINTER(_int)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],

@@ -142,3 +142,178 @@ extern "C" int stein_score_glm(const float* theta, int64_t n, int64_t d, int kin
   LAUNCH_CHECK("k_score_glm");
   return STEIN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Bayesian neural-network regression, one hidden ReLU layer (examples/regression_neural_network/main.py:29-85):
+//   pred_b = sum_h relu(sum_f x_bf w1_fh + b1_h) w2_h + b2
+//   log p = [ s * sum_b log N(y_b; pred_b, 1/gamma) + log Gamma(lambda; a, b) + log Gamma(gamma; a, b)
+//             + sum over w1, b1, w2, b2 of log N(.; 0, 1/lambda) ] / n_train,     s = n_train / n_batch,
+//   lambda = exp(log_lambda), gamma = exp(log_gamma) (densities at lambda / gamma, no Jacobian)
+// With e_b = y_b - pred_b, a_bh = relu(z_bh), m_bh = [z_bh > 0]:
+//   d/dw2_h  = (s gamma sum_b e_b a_bh        - lambda w2_h ) / n_train
+//   d/db2    = (s gamma sum_b e_b             - lambda b2   ) / n_train
+//   d/db1_h  = (s gamma sum_b e_b w2_h m_bh   - lambda b1_h ) / n_train
+//   d/dw1_fh = (s gamma sum_b e_b w2_h m_bh x_bf - lambda w1_fh) / n_train
+//   d/dlog gamma  = (s (B/2 - gamma/2 sum_b e_b^2) + (a - 1) - b gamma) / n_train
+//   d/dlog lambda = (P/2 - lambda/2 sum w^2 + (a - 1) - b lambda) / n_train,   P = F H + 2 H + 1 weights
+// LP lanes per particle over the hidden units (KH per lane); the weights and their gradients stay in registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int BNN_FMAX = 4;   // input features held in registers per hidden unit
+
+struct BnnCols { int w1, b1, w2, b2, loglam, loggam; };
+
+template <int KH, int LP>
+__global__ __launch_bounds__(256) void k_score_bnn(const float* __restrict__ theta, int n, int d, int F, int H, BnnCols c,
+                                                   const float* __restrict__ X, const float* __restrict__ y, int B,
+                                                   int chunk_rows, float n_train, float ga, float gb,
+                                                   float* __restrict__ score) {
+  extern __shared__ float lds[];   // [chunk_rows][F] X, then [chunk_rows] y
+  float* xs = lds;
+  float* ys = lds + (size_t)chunk_rows * F;
+  constexpr int PPB = 4 * (64 / LP);
+  const int t = threadIdx.x, lane = t % LP, sub = t / LP;
+  const int nchunks = (B + chunk_rows - 1) / chunk_rows;
+  auto stage = [&](int c0) {
+    const int rows = min(chunk_rows, B - c0);
+    for (int i = t; i < rows * F; i += 256) xs[i] = X[(size_t)c0 * F + i];
+    for (int i = t; i < rows; i += 256) ys[i] = y[c0 + i];
+  };
+  if (nchunks == 1) {
+    stage(0);
+    __syncthreads();
+  }
+  for (long p0 = (long)blockIdx.x * PPB; p0 < n; p0 += (long)gridDim.x * PPB) {
+    const long p = p0 + sub;
+    const bool live = p < n;
+    const float* th = theta + (size_t)(live ? p : 0) * d;
+    float w1[BNN_FMAX][KH], b1[KH], w2[KH], gw1[BNN_FMAX][KH], gb1[KH], gw2[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int h = lane + LP * k;
+      const bool ok = live && h < H;
+      b1[k] = ok ? th[c.b1 + h] : 0.f;
+      w2[k] = ok ? th[c.w2 + h] : 0.f;
+      gb1[k] = 0.f; gw2[k] = 0.f;
+#pragma unroll
+      for (int f = 0; f < BNN_FMAX; ++f) {
+        w1[f][k] = (ok && f < F) ? th[c.w1 + f * H + h] : 0.f;
+        gw1[f][k] = 0.f;
+      }
+    }
+    const float b2 = live ? th[c.b2] : 0.f;
+    float se = 0.f, se2 = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (nchunks > 1) {
+        __syncthreads();
+        stage(ch * chunk_rows);
+        __syncthreads();
+      }
+      const int rows = min(chunk_rows, B - ch * chunk_rows);
+      for (int b = 0; b < rows; ++b) {
+        float xb[BNN_FMAX];
+#pragma unroll
+        for (int f = 0; f < BNN_FMAX; ++f) xb[f] = f < F ? xs[(size_t)b * F + f] : 0.f;
+        float z[KH], part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+          float v = b1[k];
+#pragma unroll
+          for (int f = 0; f < BNN_FMAX; ++f) v = fmaf(xb[f], w1[f][k], v);
+          z[k] = v;
+          part = fmaf(fmaxf(v, 0.f), w2[k], part);
+        }
+        const float e = ys[b] - (group_sum<LP>(part) + b2);
+        se += e;
+        se2 = fmaf(e, e, se2);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+          gw2[k] = fmaf(e, fmaxf(z[k], 0.f), gw2[k]);
+          const float tk = z[k] > 0.f ? e * w2[k] : 0.f;
+          gb1[k] += tk;
+#pragma unroll
+          for (int f = 0; f < BNN_FMAX; ++f) gw1[f][k] = fmaf(tk, xb[f], gw1[f][k]);
+        }
+      }
+    }
+    float sw2 = 0.f;   // sum of squares of every weight under the N(0, 1/lambda) prior
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      sw2 = fmaf(b1[k], b1[k], fmaf(w2[k], w2[k], sw2));
+#pragma unroll
+      for (int f = 0; f < BNN_FMAX; ++f) sw2 = fmaf(w1[f][k], w1[f][k], sw2);
+    }
+    sw2 = group_sum<LP>(sw2) + b2 * b2;
+    if (live) {
+      const float lam = expf(th[c.loglam]), gam = expf(th[c.loggam]);
+      const float s = n_train / (float)B, cg = s * gam, inv = 1.f / n_train;
+      float* out = score + (size_t)p * d;
+      for (int j = lane; j < d; j += LP) {   // columns outside the model carry no gradient
+        const bool in_model = (j >= c.w1 && j < c.w1 + F * H) || (j >= c.b1 && j < c.b1 + H) || (j >= c.w2 && j < c.w2 + H) ||
+                              j == c.b2 || j == c.loglam || j == c.loggam;
+        if (!in_model) out[j] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        const int h = lane + LP * k;
+        if (h < H) {
+          out[c.b1 + h] = (cg * gb1[k] - lam * b1[k]) * inv;
+          out[c.w2 + h] = (cg * gw2[k] - lam * w2[k]) * inv;
+#pragma unroll
+          for (int f = 0; f < BNN_FMAX; ++f)
+            if (f < F) out[c.w1 + f * H + h] = (cg * gw1[f][k] - lam * w1[f][k]) * inv;
+        }
+      }
+      if (lane == 0) {
+        const float P = (float)(F * H + 2 * H + 1);
+        out[c.b2] = (cg * se - lam * b2) * inv;
+        out[c.loggam] = (s * (0.5f * (float)B - 0.5f * gam * se2) + (ga - 1.f) - gb * gam) * inv;
+        out[c.loglam] = (0.5f * P - 0.5f * lam * sw2 + (ga - 1.f) - gb * lam) * inv;
+      }
+    }
+  }
+}
+
+extern "C" int stein_score_bnn(const float* theta, int64_t n, int64_t d, int64_t n_in, int64_t n_hidden,
+                               const int64_t* cols /*[6]: w1, b1, w2, b2, log_lambda, log_gamma*/, const float* X,
+                               const float* y, int64_t batch, double n_train, double gamma_a, double gamma_b,
+                               float* score, void* stream) {
+  if (!theta || !cols || !X || !y || !score) return stein_fail(STEIN_E_BADARG, "NULL pointer");
+  if (n < 1 || d < 1 || batch < 1 || n_in < 1 || n_hidden < 1 || n > 0x7fffffffl || d > 0x7fffffffl || batch > 0x7fffffffl)
+    return stein_fail(STEIN_E_SHAPE, "bad shape");
+  if (n_in > BNN_FMAX) return stein_fail(STEIN_E_UNSUPPORTED, "more than %d input features", BNN_FMAX);
+  if (n_hidden > 1024) return stein_fail(STEIN_E_UNSUPPORTED, "more than 1024 hidden units");
+  const int64_t len[6] = {n_in * n_hidden, n_hidden, n_hidden, 1, 1, 1};
+  for (int i = 0; i < 6; ++i) {
+    if (cols[i] < 0 || cols[i] + len[i] > d) return stein_fail(STEIN_E_SHAPE, "block %d does not fit d=%lld", i, (long long)d);
+    for (int j = 0; j < i; ++j)
+      if (cols[i] < cols[j] + len[j] && cols[j] < cols[i] + len[i]) return stein_fail(STEIN_E_SHAPE, "blocks %d and %d overlap", j, i);
+  }
+  if (!(n_train > 0.0)) return stein_fail(STEIN_E_BADARG, "n_train must be positive");
+  BnnCols c = {(int)cols[0], (int)cols[1], (int)cols[2], (int)cols[3], (int)cols[4], (int)cols[5]};
+  int64_t chunk_rows = SC_MAXLDS / (n_in + 1);
+  if (chunk_rows > batch) chunk_rows = batch;
+  const size_t lds_bytes = (size_t)chunk_rows * (n_in + 1) * sizeof(float);
+  const int lp = n_hidden <= 128 ? 16 : 64;
+  const int ppb = 4 * (64 / lp);
+  long blocks = (long)((n + ppb - 1) / ppb);
+  if (blocks > 4096) blocks = 4096;
+  const int kh = (int)((n_hidden + lp - 1) / lp);
+  hipStream_t s = (hipStream_t)stream;
+#define BNN_LAUNCH(KH, LP)                                                                                             \
+  hipLaunchKernelGGL((k_score_bnn<KH, LP>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, theta, (int)n, (int)d,     \
+                     (int)n_in, (int)n_hidden, c, X, y, (int)batch, (int)chunk_rows, (float)n_train, (float)gamma_a,    \
+                     (float)gamma_b, score)
+  if (lp == 16) {
+    if (kh <= 1) BNN_LAUNCH(1, 16);
+    else if (kh <= 2) BNN_LAUNCH(2, 16);
+    else if (kh <= 4) BNN_LAUNCH(4, 16);
+    else BNN_LAUNCH(8, 16);
+  } else {
+    if (kh <= 4) BNN_LAUNCH(4, 64);
+    else if (kh <= 8) BNN_LAUNCH(8, 64);
+    else BNN_LAUNCH(16, 64);
+  }
+#undef BNN_LAUNCH
+  LAUNCH_CHECK("k_score_bnn");
+  return STEIN_OK;
+}

@@ -49,3 +49,42 @@ class GlmScore:
                   X.data_ptr(), y.data_ptr(), batch, scale, self.prior_precision, self.gamma_rate, out.data_ptr(),
                   torch.cuda.current_stream(theta.device).cuda_stream)
         return out
+
+
+class BnnScore:
+    """Score of the one-hidden-layer Bayesian neural-network regression model of
+    examples/regression_neural_network/main.py:29-85 (ReLU, Gamma(a, b) priors on the weight precision lambda and the
+    noise precision gamma, both sampled in log space), for every particle in one launch.
+
+    cols: first column of (w1, b1, w2, b2, log_lambda, log_gamma) in the packed particle matrix -- use
+    ``BnnScore.columns(sampler)`` for a SteinSampler built with the variable names of the example.
+    """
+    wants_matrix = True
+    NAMES = ("model/w_1:0", "model/b_1:0", "model/w_2:0", "model/b_2:0", "model/log_lambda:0", "model/log_gamma:0")
+
+    def __init__(self, n_in, n_hidden, cols, n_train, gamma_a=1.0, gamma_b=0.01):
+        import ctypes
+        self.n_in, self.n_hidden, self.n_train = int(n_in), int(n_hidden), float(n_train)
+        self.gamma_a, self.gamma_b = float(gamma_a), float(gamma_b)
+        self._cols = (ctypes.c_int64 * 6)(*[int(c) for c in cols])
+
+    @staticmethod
+    def columns(access, names=NAMES):
+        """first packed column of each parameter block from a sampler's access map {name: (start, end)}"""
+        return tuple(access[k][0] for k in names)
+
+    def __call__(self, theta, feed, out=None):
+        X, y = feed["X"], feed["y"]
+        for name, t in (("theta", theta), ("X", X), ("y", y)):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("%s must be a contiguous float32 device tensor" % name)
+        n, d = theta.shape
+        batch = X.shape[0]
+        if X.shape != (batch, self.n_in) or y.numel() != batch:
+            raise ValueError("X must be [batch, %d] and y [batch]" % self.n_in)
+        if out is None:
+            out = torch.empty_like(theta)
+        _lib.call("stein_score_bnn", theta.data_ptr(), n, d, self.n_in, self.n_hidden, self._cols, X.data_ptr(),
+                  y.data_ptr(), batch, self.n_train, self.gamma_a, self.gamma_b, out.data_ptr(),
+                  torch.cuda.current_stream(theta.device).cuda_stream)
+        return out

@@ -72,3 +72,44 @@ def test_bad_arguments_are_refused(cuda):
         GlmScore("logistic", 3, w_col=0, alpha_col=1)(t, feed)     # log-alpha inside the weights
     with pytest.raises(ValueError):
         GlmScore("logistic", 4)(t, feed)                           # X has 3 features
+
+
+@pytest.mark.parametrize("n,n_in,H,batch", [(5, 1, 3, 4), (40, 1, 100, 20), (33, 2, 70, 50), (17, 4, 300, 9), (9, 1, 666, 20)])
+def test_bnn_score_matches_oracle(cuda, n, n_in, H, batch):
+    from stein_amd.scores import BnnScore
+    rng = np.random.default_rng(n + H)
+    # packed order of the reference's variables (sorted TF names): log_lambda, log_gamma, w_1, b_1, w_2, b_2, + a spare column
+    cols = (2, 2 + n_in * H, 2 + n_in * H + H, 2 + n_in * H + 2 * H, 0, 1)
+    d = 2 + n_in * H + 2 * H + 1 + 1
+    th = rng.normal(size=(n, d)) * 0.7
+    X, y = rng.uniform(size=(batch, n_in)), rng.normal(size=batch)
+    th32, X32, y32 = (a.astype(np.float32).astype(np.float64) for a in (th, X, y))
+    ref = so.bnn_score_matrix(th32, n_in, H, cols, X32, y32, n_train=float(5 * batch))
+    got = BnnScore(n_in, H, cols, n_train=5 * batch)(
+        torch.tensor(th, dtype=torch.float32, device=cuda),
+        {"X": torch.tensor(X, dtype=torch.float32, device=cuda), "y": torch.tensor(y, dtype=torch.float32, device=cuda)})
+    got = got.double().cpu().numpy()
+    assert (got[:, -1] == 0).all()
+    assert np.abs(got - ref).max() <= 3e-5 * np.abs(ref).max() + 1e-7, np.abs(got - ref).max() / np.abs(ref).max()
+
+
+def test_bnn_score_matches_autograd_of_the_example(cuda):
+    import importlib.util
+    import os
+    from stein_amd.scores import BnnScore
+    spec = importlib.util.spec_from_file_location(
+        "bnn_example", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                                    "regression_neural_network", "main.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    n, B = 64, 20
+    shapes = {"model/w_1:0": [1, ex.H], "model/b_1:0": [ex.H], "model/w_2:0": [ex.H, 1], "model/b_2:0": [],
+              "model/log_lambda:0": [], "model/log_gamma:0": []}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    feed = {"X": torch.rand(B, 1, generator=g).to(cuda), "y": torch.randn(B, generator=g).to(cuda)}
+    init = {k: torch.randn([n] + s, generator=g).numpy() for k, s in shapes.items()}
+    auto = SteinSampler(n, ex.make_log_posterior(B, B), AdamGradientDescent(1e-2), theta=init, model_vars=shapes, device=cuda)
+    hip = SteinSampler(n, None, AdamGradientDescent(1e-2), theta=init, model_vars=shapes, device=cuda,
+                       score=BnnScore(1, ex.H, BnnScore.columns(auto._access), n_train=B))
+    a, b = auto.score_matrix(feed), hip.score_matrix(feed)
+    assert (a - b).abs().max() <= 2e-5 * a.abs().max()

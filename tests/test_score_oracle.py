@@ -39,3 +39,14 @@ def test_matrix_packing():
     assert (S[:, 0] == 0).all() and (S[:, 5] == 0).all()
     gw, ga = so.logistic_score(th[3, 2:5], th[3, 1], X, y, 2.0)
     assert np.allclose(S[3, 2:5], gw) and np.isclose(S[3, 1], ga)
+
+
+def test_bnn_score_matches_finite_differences():
+    rng = np.random.default_rng(3)
+    n_in, H, B = 2, 7, 12
+    X, y = rng.uniform(size=(B, n_in)), rng.normal(size=B)
+    cols = (2, 2 + n_in * H, 2 + n_in * H + H, 2 + n_in * H + 2 * H, 0, 1)      # log_lambda, log_gamma first, as the reference sorts them
+    row = rng.normal(size=2 + n_in * H + 2 * H + 1)
+    f = lambda v: so.bnn_log_p(so.bnn_unpack(v, n_in, H, cols), X, y, n_train=40.0)
+    g = so.bnn_score_matrix(row[None, :], n_in, H, cols, X, y, n_train=40.0)[0]
+    assert np.allclose(g, _fd(f, row), rtol=1e-5, atol=1e-7)
