@@ -21,6 +21,7 @@ HIST_BINS, HIST_LEVELS = 2048, 3
 STAGE_SYMMETRIC = 1
 FLAG_X3 = 1
 FLAG_TIMING = 4
+FLAG_TILED = 8
 GLM_LINEAR, GLM_LOGISTIC = 0, 1
 SPEC_TABLE_WORDS = 65544          # uint64 words of the rank-summed window table ...
 SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC section (slots + entry buffer)

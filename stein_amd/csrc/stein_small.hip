@@ -1,0 +1,241 @@
+// stein_small.hip -- the whole phi computation in ONE kernel for the particle counts the reference's own examples
+// use (n = 20 ... 100): at that size the staged pipeline is ~25 launches of a few microseconds each and nothing
+// else.  Every workgroup redundantly computes the row norms, the n x n distance matrix (kept in LDS), its exact
+// median (the same 3-level radix select on the order-preserving key, here on LDS histograms) and K, then forms phi
+// for its own block of SM_COLS parameter columns; one small reduction kernel sums the per-workgroup |phi|^2.
+//
+//   D_ij = r_i + r_j - 2 theta_i . theta_j  (fp32)          stein/kernels/abstract_kernel.py:33-35
+//   med  = median of all n^2 entries, even count -> mean     stein/utilities/compute_median.py:4-16
+//   h2   = sqrt(med / ln n)^2                                abstract_kernel.py:40, squared_exponential_kernel.py:22
+//   K    = exp(-D / h2 / 2);  dK = (rowsum(K) theta - K theta) / h2     squared_exponential_kernel.py:22-35
+//   phi  = (K G + dK) / n                                    stein/samplers/abstract_stein_sampler.py:100-105
+#include "stein_common.h"
+
+constexpr int SM_MAXN = 128;      // particles (the distance matrix lives in LDS: 128 x 129 floats = 66 KB)
+constexpr int SM_THREADS = 1024;
+constexpr int SM_COLS = 32;       // parameter columns per workgroup (their theta / score columns are staged in LDS)
+constexpr int SM_CK = 32;         // columns of theta staged per pass of the distance loop
+static_assert(SM_COLS == SM_CK, "the theta chunk buffer doubles as the phi stage's theta block");
+constexpr int SM_PAIRS = (SM_MAXN * (SM_MAXN + 1) / 2 + SM_THREADS - 1) / SM_THREADS;   // pairs (i <= j) per thread: 9
+
+__device__ __forceinline__ void sm_pair(int p, int n, int& i, int& j) {   // p-th pair of the upper triangle, row by row
+  int row = (int)(((2.0f * n + 1.0f) - sqrtf((2.0f * n + 1.0f) * (2.0f * n + 1.0f) - 8.0f * (float)p)) * 0.5f);
+  row = max(0, min(row, n - 1));
+  while (row > 0 && row * n - row * (row - 1) / 2 > p) --row;
+  while ((row + 1) * n - (row + 1) * row / 2 <= p) ++row;
+  i = row;
+  j = row + (p - (row * n - row * (row - 1) / 2));
+}
+
+__global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restrict__ T, const float* __restrict__ G, int n,
+                                                           int d, float ln_n, float* __restrict__ phi,
+                                                           float* __restrict__ h2_out, double* __restrict__ sqpart,
+                                                           float* __restrict__ K_out, float* __restrict__ dK_out) {
+  extern __shared__ float sm[];
+  const int ldn = n + 1;
+  float* Dm = sm;                                   // [n][n + 1]  distances, then K
+  float* tc = Dm + (size_t)n * ldn;                 // [n][SM_CK + 1] theta chunk
+  float* rn = tc + (size_t)n * (SM_CK + 1);         // [n] row norms, later rowsum(K)
+  u32* hist = reinterpret_cast<u32*>(rn + n);       // [2][2048]
+  __shared__ u32 s_prefix[2], s_rank[2], s_div, s_wsum[SM_THREADS / 64];
+  __shared__ float s_h2;
+  __shared__ double s_red[SM_THREADS / 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int npairs = n * (n + 1) / 2;
+
+  // ---- row norms (abstract_kernel.py:34): one wave per row ----
+  for (int i = wave; i < n; i += SM_THREADS / 64) {
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = T[(size_t)i * d + c]; s = fmaf(v, v, s); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rn[i] = s;
+  }
+  // ---- S = T T^T over the upper triangle, theta staged SM_CK columns at a time ----
+  int pi[SM_PAIRS], pj[SM_PAIRS];
+  float acc[SM_PAIRS];
+#pragma unroll
+  for (int k = 0; k < SM_PAIRS; ++k) {
+    const int p = t + k * SM_THREADS;
+    pi[k] = pj[k] = 0;
+    if (p < npairs) sm_pair(p, n, pi[k], pj[k]);
+    acc[k] = 0.f;
+  }
+  for (int c0 = 0; c0 < d; c0 += SM_CK) {
+    __syncthreads();
+    for (int e = t; e < n * SM_CK; e += SM_THREADS) {
+      const int i = e / SM_CK, c = e % SM_CK;
+      tc[i * (SM_CK + 1) + c] = c0 + c < d ? T[(size_t)i * d + c0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SM_PAIRS; ++k) {
+      const float* a = tc + pi[k] * (SM_CK + 1);
+      const float* b = tc + pj[k] * (SM_CK + 1);
+      float s = acc[k];
+      if (c0 + SM_CK <= d) {
+#pragma unroll
+        for (int c = 0; c < SM_CK; ++c) s = fmaf(a[c], b[c], s);
+      } else {
+        for (int c = 0; c < d - c0; ++c) s = fmaf(a[c], b[c], s);
+      }
+      acc[k] = s;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SM_PAIRS; ++k) {
+    const int p = t + k * SM_THREADS;
+    if (p < npairs) {
+      const float v = (rn[pi[k]] + rn[pj[k]]) - 2.f * acc[k];      // abstract_kernel.py:35
+      Dm[pi[k] * ldn + pj[k]] = v;
+      Dm[pj[k] * ldn + pi[k]] = v;
+    }
+  }
+  // ---- exact median of the n^2 entries: 3-level radix select (11 / 11 / 10 bits), two targets for an even count ----
+  const u32 total = (u32)n * (u32)n;
+  if (t == 0) {
+    s_rank[0] = (total & 1u) ? total / 2 : total / 2 - 1;
+    s_rank[1] = total / 2;
+    s_prefix[0] = s_prefix[1] = 0u;
+    s_div = 0u;
+  }
+  for (int level = 0; level < 3; ++level) {
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0), bits = level == 2 ? 10 : 11;
+    for (int b = t; b < 2 * STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;
+    __syncthreads();
+    const u32 pa = s_prefix[0], pb = s_prefix[1];
+    const bool two = s_div != 0u;
+    for (u32 e = t; e < total; e += SM_THREADS) {
+      const u32 key = f32_key(Dm[(e / n) * ldn + (e % n)]);
+      const u32 digit = (key >> shift) & ((1u << bits) - 1u);
+      const u32 hi = level == 0 ? 0u : key >> (shift + bits);
+      if (level == 0 || hi == pa) atomicAdd(&hist[digit], 1u);
+      if (two && hi == pb) atomicAdd(&hist[STEIN_HIST_BINS + digit], 1u);
+    }
+    __syncthreads();
+    // locate each target's digit with a workgroup-wide prefix sum over the 2048 bins (two bins per thread); a
+    // single thread walking the bins took 65 us per level
+    for (int tg = 0; tg < 2; ++tg) {
+      const u32* h = hist + ((two && tg == 1) ? STEIN_HIST_BINS : 0);
+      const u32 c0 = h[2 * t], c1 = h[2 * t + 1];
+      u32 incl = c0 + c1;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) s_wsum[wave] = incl;
+      __syncthreads();
+      u32 base = 0u;
+      for (int w = 0; w < wave; ++w) base += s_wsum[w];
+      const u32 excl = base + incl - (c0 + c1);
+      const u32 rank = s_rank[tg];
+      __syncthreads();   // everybody has read s_rank / s_wsum before they change
+      if (rank >= excl && rank < excl + c0 + c1) {   // exactly one thread (the counts sum to more than rank)
+        const u32 b = rank < excl + c0 ? 2u * t : 2u * t + 1u;
+        s_prefix[tg] = (s_prefix[tg] << bits) | b;
+        s_rank[tg] = rank - (b & 1u ? excl + c0 : excl);
+      }
+      __syncthreads();
+    }
+    if (t == 0) s_div = s_prefix[0] != s_prefix[1] ? 1u : 0u;
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float lo = key_f32(s_prefix[0]), hi = key_f32(s_prefix[1]);
+    const float med = (total & 1u) ? lo : 0.5f * (lo + hi);        // compute_median.py:12-15
+    const float bw = sqrtf(med / ln_n);                             // abstract_kernel.py:40
+    s_h2 = bw * bw;                                                 // squared_exponential_kernel.py:22
+    if (blockIdx.x == 0) *h2_out = s_h2;
+  }
+  __syncthreads();
+  const float h2 = s_h2;
+  // ---- K in place, rowsum(K) ----
+  for (u32 e = t; e < total; e += SM_THREADS) {
+    const int i = e / n, j = e % n;
+    const float k = expf(-Dm[i * ldn + j] / h2 / 2.f);
+    Dm[i * ldn + j] = k;
+    if (K_out && blockIdx.x == 0) K_out[(size_t)i * n + j] = k;
+  }
+  __syncthreads();
+  for (int i = wave; i < n; i += SM_THREADS / 64) {
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += Dm[i * ldn + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rn[i] = s;
+  }
+  __syncthreads();
+  // ---- phi for this workgroup's SM_COLS columns.  Their theta / score columns are staged in LDS first (the chunk
+  //      buffer and the histograms are free now): read from global memory inside the j loop, every iteration paid
+  //      the L2 latency (30+ us at n = 100).  thread -> (row i, column c), lanes along c ----
+  const int cw0 = blockIdx.x * SM_COLS;
+  const int ncols = min(SM_COLS, d - cw0);
+  float* ts = tc;                                    // [n][SM_COLS + 1]
+  float* gs = reinterpret_cast<float*>(hist);        // [n][SM_COLS]   (2 * 2048 words >= 128 * 32)
+  for (int e = t; e < n * SM_COLS; e += SM_THREADS) {
+    const int j = e / SM_COLS, cl = e % SM_COLS;
+    const bool ok = cl < ncols;
+    ts[j * (SM_COLS + 1) + cl] = ok ? T[(size_t)j * d + cw0 + cl] : 0.f;
+    gs[j * SM_COLS + cl] = ok ? G[(size_t)j * d + cw0 + cl] : 0.f;
+  }
+  __syncthreads();
+  // one wave per row i: lane -> column (lane & 31) and half of the j range (lane >> 5); K_ij is a broadcast read, the
+  // staged score / theta entries of 32 consecutive lanes are consecutive words
+  double sq = 0.0;
+  const float fn = (float)n;
+  const int cl = lane & 31, jh = lane >> 5;
+  const int jmid = (n + 1) / 2, j0 = jh ? jmid : 0, j1 = jh ? n : jmid;
+  for (int i = wave; i < n; i += SM_THREADS / 64) {
+    const float* krow = Dm + i * ldn;
+    float kg = 0.f, kt = 0.f;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+      const float k = krow[j];
+      kg = fmaf(k, gs[j * SM_COLS + cl], kg);
+      kt = fmaf(k, ts[j * (SM_COLS + 1) + cl], kt);
+    }
+    kg += __shfl_xor(kg, 32);
+    kt += __shfl_xor(kt, 32);
+    if (jh == 0 && cl < ncols) {
+      const int c = cw0 + cl;
+      const float dk = (rn[i] * ts[i * (SM_COLS + 1) + cl] - kt) / h2;   // squared_exponential_kernel.py:28-35
+      const float ph = (kg + dk) / fn;                                    // abstract_stein_sampler.py:105
+      phi[(size_t)i * d + c] = ph;
+      if (dK_out) dK_out[(size_t)i * d + c] = dk;
+      sq += (double)ph * (double)ph;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) s_red[wave] = sq;
+  __syncthreads();
+  if (t == 0) {
+    double s = 0.0;
+    for (int w = 0; w < SM_THREADS / 64; ++w) s += s_red[w];
+    sqpart[blockIdx.x] = s;
+  }
+}
+
+// the caller (stein_svgd_phi) checks applicability with stein_small_ok first
+bool stein_small_ok(int64_t n, int64_t d, int dtype) {
+  static const bool off = [] { const char* e = getenv("STEIN_SMALL"); return e && e[0] == '0'; }();
+  return !off && dtype == STEIN_F32 && n >= 2 && n <= SM_MAXN && n * n * d <= (4ll << 20) && (d + SM_COLS - 1) / SM_COLS <= 1024;
+}
+
+int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
+                    double* sqpart, float* K_out, float* dK_out, int* nparts, hipStream_t stream) {
+  const int blocks = (int)((d + SM_COLS - 1) / SM_COLS);
+  const size_t lds = ((size_t)n * (n + 1) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + 2 * STEIN_HIST_BINS * sizeof(u32);
+  static bool attr_set = false;
+  if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svgd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                120 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_svgd_small, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, theta, score, (int)n, (int)d,
+                     (float)log((double)n), phi, h2_out, sqpart, K_out, dK_out);
+  LAUNCH_CHECK("k_svgd_small");
+  *nparts = blocks;
+  return STEIN_OK;
+}

@@ -758,7 +758,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
-  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -802,7 +802,10 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   put(STEIN_WS_PART_G, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_T, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_RS, (size_t)split * n_local * 4);
-  put(STEIN_WS_SQPART, (size_t)sqb * 8);
+  {  // k_phi_finish writes sq_blocks partials, the one-kernel small path one per 32 parameter columns
+    const int64_t small = (d + 31) / 32;
+    put(STEIN_WS_SQPART, (size_t)(sqb > small ? sqb : small) * 8);
+  }
   put(STEIN_WS_SPEC, ((size_t)SPEC_CAP + SPEC_SLOTS * 8 + SPEC_TABLE) * 8);   // slots | entries | rank-summed table
   // split operand planes: always LAST so the offsets above do not depend on the flag
   L->x3_rows = (int64_t)align_up((size_t)n, 128) + 128;   // a rank's last row tile may start past roundup(n, 128) - 128
@@ -1187,6 +1190,21 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     tev = &g_tevents[(size_t)(g_tcalls_used++) * (STEIN_T_NSTAGES + 1)];
 #define STEIN_TSTAMP(k) do { if (tev) HIP_TRY(hipEventRecord(tev[k], s)); } while (0)
   STEIN_TSTAMP(STEIN_T_PREPARE);
+  if (!(flags & STEIN_FLAG_TILED) && stein_small_ok(n, d, dtype)) {   // the reference's own example sizes: one kernel does it all (stein_small.hip)
+    STEIN_TSTAMP(STEIN_T_DISTANCE);
+    STEIN_TSTAMP(STEIN_T_MEDIAN);
+    STEIN_TSTAMP(STEIN_T_CONTRACT);
+    int nparts = 0;
+    double* sqp = (double*)(ws + L.off[STEIN_WS_SQPART]);
+    if ((rc = stein_small_phi((const float*)theta_all, (const float*)score_all, n, d, phi_local, h2_out, sqp, K_out,
+                              dK_out, &nparts, s)))
+      return rc;
+    STEIN_TSTAMP(STEIN_T_FINISH);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const double*)sqp, nparts, sqnorm_out);
+    LAUNCH_CHECK("k_sum_partials");
+    STEIN_TSTAMP(STEIN_T_NSTAGES);
+    return STEIN_OK;
+  }
   if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
   if (planes && (rc = stein_x3_prepare(theta_all, score_all, n, d, dtype, planes, L.total - L.off[STEIN_WS_PLANES], stream)))
     return rc;

@@ -137,7 +137,7 @@ class SvgdEngine:
               (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
     """
 
-    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32):
+    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True):
         self.n, self.d = int(n), int(d)
         # dtype of the theta / score tensors handed to compute_phi: float32, or bfloat16 (BASELINE config 2: the
         # values are used as they are, K is rounded to bf16, one bf16 MFMA per product, fp32 accumulation)
@@ -150,7 +150,8 @@ class SvgdEngine:
         if x3 is None:
             x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
         self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
-        self.flags = _lib.FLAG_X3 if self.x3 else 0
+        # small=False: the fused call never takes the one-kernel path for n <= 128 (tests of the tiled kernels)
+        self.flags = (_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED)
         # several ranks: use the speculative median window (one 512 KB all-reduce and a hit-flag read-back per step
         # instead of two passes over the local distance block) when the block is large enough for that to pay;
         # STEIN_DIST_WINDOW=0/1 forces it

@@ -46,7 +46,7 @@ def test_stages_match_oracle(cuda, n, d):
     T64, G64 = _inputs(n, d)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    eng = SvgdEngine(n, d, device=cuda, x3=False)
+    eng = SvgdEngine(n, d, device=cuda, x3=False, small=False)
     dK = _staged(eng, T, G)
 
     T32 = T.cpu().numpy()
@@ -85,7 +85,7 @@ def test_fused_equals_staged(cuda, n, d):
     T64, G64 = _inputs(n, d, seed=3)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    eng = SvgdEngine(n, d, device=cuda, x3=False)
+    eng = SvgdEngine(n, d, device=cuda, x3=False, small=False)
     _staged(eng, T, G)
     phi_staged, h2_staged, sq_staged = eng.phi.clone(), eng.h2.clone(), eng.sqnorm.clone()
     D_staged, hist_staged = eng.dist_matrix(), eng.hist.clone()
@@ -110,7 +110,7 @@ def test_kernel_matrix_output(cuda):
     n, d = 257, 33
     T64, _ = _inputs(n, d, seed=5)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
-    eng = SvgdEngine(n, d, device=cuda, x3=False)
+    eng = SvgdEngine(n, d, device=cuda, x3=False, small=False)
     K = torch.empty(n, n, dtype=torch.float32, device=cuda)
     dK = torch.empty(n, d, dtype=torch.float32, device=cuda)
     eng.compute_phi(T, T, K_out=K, dK_out=dK)
@@ -132,7 +132,7 @@ def test_clustered_particles_with_offset(cuda):
     G64 = rng.normal(size=(n, d))
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    eng = SvgdEngine(n, d, device=cuda, x3=False)
+    eng = SvgdEngine(n, d, device=cuda, x3=False, small=False)
     phi = eng.compute_phi(T, G).cpu().numpy()
     ref64 = orc.svgd_step(T.cpu().numpy().astype(np.float64), G.cpu().numpy().astype(np.float64), orc.AdagradState(), np.float64)
     ref32 = orc.svgd_step(T.cpu().numpy().astype(np.float64), G.cpu().numpy().astype(np.float64), orc.AdagradState(), np.float32)
@@ -147,7 +147,7 @@ def test_translation_and_permutation_properties(cuda):
     T64, G64 = _inputs(n, d, seed=11)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    eng = SvgdEngine(n, d, device=cuda, x3=False)
+    eng = SvgdEngine(n, d, device=cuda, x3=False, small=False)
     base = eng.compute_phi(T, G).clone()
     perm = torch.randperm(n, device=cuda)
     permuted = eng.compute_phi(T[perm].contiguous(), G[perm].contiguous()).clone()
@@ -175,7 +175,7 @@ def test_identical_particles_are_nan_like_reference(cuda):
     """All particles equal -> median 0 -> bandwidth 0 -> exp(-0/0): the reference yields NaN; so do we (no crash)."""
     T = torch.ones(32, 8, device=cuda)
     G = torch.ones(32, 8, device=cuda)
-    eng = SvgdEngine(32, 8, device=cuda, x3=False)
+    eng = SvgdEngine(32, 8, device=cuda, x3=False, small=False)
     phi = eng.compute_phi(T, G)
     torch.cuda.synchronize()
     assert eng.median.item() == 0.0

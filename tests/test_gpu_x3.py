@@ -33,7 +33,7 @@ def test_split_planes_reconstruct_fp32(cuda):
     T64[0, 0], T64[1, 1], T64[2, 2] = 0.0, 1e-30, -3.0e20
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    eng = SvgdEngine(n, d, device=cuda, x3=True)
+    eng = SvgdEngine(n, d, device=cuda, x3=True, small=False)
     eng.stages.x3_prepare(T, G, n, d, eng.planes)
     torch.cuda.synchronize()
     kind = _split_kind()
@@ -79,9 +79,9 @@ def test_x3_matches_oracle_and_fp32_path(cuda, n, d):
     T64, G64 = _inputs(n, d)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    ref_eng = SvgdEngine(n, d, device=cuda, x3=False)
+    ref_eng = SvgdEngine(n, d, device=cuda, x3=False, small=False)
     phi32 = ref_eng.compute_phi(T, G).clone()
-    eng = SvgdEngine(n, d, device=cuda, x3=True)
+    eng = SvgdEngine(n, d, device=cuda, x3=True, small=False)
     dK = torch.empty(n, d, device=cuda)
     phi = eng.compute_phi(T, G, dK_out=dK).clone()
     torch.cuda.synchronize()
@@ -125,7 +125,7 @@ def test_x3_error_is_fp32_level_at_c2_size(cuda):
     ref = (K @ G64 + (K.sum(1)[:, None] * T64 - K @ T64) / h2) / n
     e = {}
     for x3 in (False, True):
-        eng = SvgdEngine(n, d, device=cuda, x3=x3)
+        eng = SvgdEngine(n, d, device=cuda, x3=x3, small=False)
         phi = eng.compute_phi(T, G).double()
         e[x3] = ((phi - ref).norm() / ref.norm()).item()
     assert e[True] <= 1e-5 and e[True] <= 4 * e[False] + 1e-7, e
@@ -138,7 +138,7 @@ def test_x3_row_blocks_match_full(cuda, n, d, parts):
     T64, G64 = _inputs(n, d, 9)
     T = torch.tensor(T64, dtype=torch.float32, device=cuda)
     G = torch.tensor(G64, dtype=torch.float32, device=cuda)
-    full = SvgdEngine(n, d, device=cuda, x3=True)
+    full = SvgdEngine(n, d, device=cuda, x3=True, small=False)
     phi_full = full.compute_phi(T, G).clone()
     nl = n // parts
     total, offs, extra = _lib.workspace_layout(nl, n, d, _lib.F32, _lib.FLAG_X3)
