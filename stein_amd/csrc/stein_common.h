@@ -103,23 +103,25 @@ struct SelState {
 };
 static_assert(sizeof(SelState) == 64, "SelState must stay 64 bytes");
 
-// Speculative median window (single-rank fused call only).  SVGD moves the particles a little per step, so the
-// median of the n^2 distances drifts smoothly.  The distance epilogue counts the entries below a narrow key window
-// around the median extrapolated from the two previous steps and appends the entries inside it to a buffer; if both median targets
-// turn out to lie inside the window, an exact weighted selection over that buffer (k_spec_select) replaces the two
-// radix-select passes over D.  Otherwise (first step, jump, overflow) the passes run as before: exact either way.
+// Speculative median window (the fused single-rank call; the staged stein_spec_* calls for several ranks).  SVGD
+// moves the particles a little per step, so the median of the n^2 distances drifts smoothly.  The distance
+// epilogue counts the entries below a narrow key window around the median extrapolated from the two previous steps
+// and appends the entries inside it to a buffer; if both median targets turn out to lie inside the window, an exact
+// weighted selection over that buffer (k_spec_select; k_spec_tally + k_spec_pick across ranks) replaces the
+// radix-select passes over D.  Otherwise (first steps, jump, overflow) the passes run as before: exact either way.
 // Lives right after SelState in the SELECT section and persists across steps (garbage until `magic` is set).
 struct SpecState {
   u32 magic;      // SPEC_MAGIC1 once one median has been recorded, SPEC_MAGIC2 once two have (velocity known)
-  u32 center;     // predicted key of this step's lower median target: last + (last - the one before), linear
-                  // extrapolation in key space (the median drifts almost linearly from step to step)
+  u32 center;     // predicted key of this step's lower median target: the VALUE is extrapolated linearly from the two
+                  // previous medians (key space bends at every power of two), then mapped to its key
   u32 halfwidth;  // half-width of the next window, in key units: follows the last prediction error
   u32 lo_key;     // this step's window [lo_key, lo_key + width]; lo_key = 0xffffffff, width = 0: no window
   u32 width;
-  u32 count;      // entries appended this step (may exceed the buffer capacity -> overflow -> miss)
+  u32 count;      // entries appended this step (may exceed the buffer capacity -> overflow -> miss); k_spec_pick
+                  // replaces it by the sum over the ranks
   u32 overflow;   // a workgroup's LDS queue overflowed
   u32 hit;        // this step's median came from the window; the radix-select passes skip themselves
-  u64 below;      // (unused: the weight below the window is summed from the slots at the head of the buffer)
+  u64 reserved;   // (the weight below the window is summed from the slots at the head of the buffer)
   u64 total;      // n * n
   u32 last_key;   // key of the previous step's lower median target
   u32 skip_l0;    // the level-0 histogram pass over D is not needed (taken in the distance epilogue, or the window hit)

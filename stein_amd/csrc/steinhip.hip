@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp
   }
   sp->count = 0u; sp->overflow = 0u; sp->hit = 0u;
   sp->skip_l0 = sp->width == 0u ? 1u : 0u;   // no window: the distance epilogue takes the level-0 histogram itself
-  sp->below = 0ull; sp->total = total;
+  sp->reserved = 0ull; sp->total = total;
 }
 
 // All 256 bins of an LDS histogram -> the bin holding 0-based rank `rank` and the rank inside it; *bin = 256 when the
