@@ -303,9 +303,10 @@ class SvgdEngine:
         if self.world > 1:
             import torch.distributed as dist
             mark("gather")
-            # the score rows are not needed before the contraction: their all-gather runs beside the distance pass
-            gather_g = dist.all_gather_into_tensor(self.G_all, score_local, group=self.group, async_op=True)
+            # theta first (collectives of one group run in issue order); the score rows are not needed before the
+            # contraction, so their all-gather is asynchronous and runs beside the distance pass
             dist.all_gather_into_tensor(self.T_all, theta_local, group=self.group)
+            gather_g = dist.all_gather_into_tensor(self.G_all, score_local, group=self.group, async_op=True)
             T_all, G_all = self.T_all, self.G_all
         else:
             T_all, G_all = theta_local, score_local
