@@ -11,21 +11,13 @@
 //   phi  = (K G + dK) / n                                    stein/samplers/abstract_stein_sampler.py:100-105
 #include "stein_common.h"
 
+#include <type_traits>
+
 constexpr int SM_MAXN = 128;      // particles (the distance matrix lives in LDS: 128 x 129 floats = 66 KB)
 constexpr int SM_THREADS = 1024;
 constexpr int SM_COLS = 32;       // parameter columns per workgroup (their theta / score columns are staged in LDS)
 constexpr int SM_CK = 32;         // columns of theta staged per pass of the distance loop
 static_assert(SM_COLS == SM_CK, "the theta chunk buffer doubles as the phi stage's theta block");
-constexpr int SM_PAIRS = (SM_MAXN * (SM_MAXN + 1) / 2 + SM_THREADS - 1) / SM_THREADS;   // pairs (i <= j) per thread: 9
-
-__device__ __forceinline__ void sm_pair(int p, int n, int& i, int& j) {   // p-th pair of the upper triangle, row by row
-  int row = (int)(((2.0f * n + 1.0f) - sqrtf((2.0f * n + 1.0f) * (2.0f * n + 1.0f) - 8.0f * (float)p)) * 0.5f);
-  row = max(0, min(row, n - 1));
-  while (row > 0 && row * n - row * (row - 1) / 2 > p) --row;
-  while ((row + 1) * n - (row + 1) * row / 2 <= p) ++row;
-  i = row;
-  j = row + (p - (row * n - row * (row - 1) / 2));
-}
 
 __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restrict__ T, const float* __restrict__ G, int n,
                                                            int d, float ln_n, float* __restrict__ phi,
@@ -41,7 +33,6 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   __shared__ float s_h2;
   __shared__ double s_red[SM_THREADS / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int npairs = n * (n + 1) / 2;
 
   // ---- row norms (abstract_kernel.py:34): one wave per row ----
   for (int i = wave; i < n; i += SM_THREADS / 64) {
@@ -51,45 +42,63 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) rn[i] = s;
   }
-  // ---- S = T T^T over the upper triangle, theta staged SM_CK columns at a time ----
-  int pi[SM_PAIRS], pj[SM_PAIRS];
-  float acc[SM_PAIRS];
+  // ---- S = T T^T, theta staged SM_CK columns at a time.  Thread (bi, bj) = (t / 32, t % 32) owns the entries
+  //      (bi + 32 r, bj + 32 s), r, s < R = ceil(n / 32): 2 R LDS reads feed R^2 FMAs per column, the row reads are
+  //      broadcasts and the column reads of 32 consecutive lanes hit 32 different banks (row stride 33).  (One thread
+  //      per (i <= j) pair read two words per FMA: 23 MB of LDS reads, 90 us, for n = 20, d = 303.) ----
+  const int bi = t >> 5, bj = t & 31;
+  const int R = (n + 31) >> 5;
+  const bool mine = bi < n && bj < n;
+  // RR = R as a compile-time constant: the inner loop is 2 RR LDS reads (fixed row offsets) and RR^2 FMAs per column
+  auto distances = [&](auto rr_tag) {
+    constexpr int RR = decltype(rr_tag)::value;
+    float acc[RR][RR];
 #pragma unroll
-  for (int k = 0; k < SM_PAIRS; ++k) {
-    const int p = t + k * SM_THREADS;
-    pi[k] = pj[k] = 0;
-    if (p < npairs) sm_pair(p, n, pi[k], pj[k]);
-    acc[k] = 0.f;
-  }
-  for (int c0 = 0; c0 < d; c0 += SM_CK) {
-    __syncthreads();
-    for (int e = t; e < n * SM_CK; e += SM_THREADS) {
-      const int i = e / SM_CK, c = e % SM_CK;
-      tc[i * (SM_CK + 1) + c] = c0 + c < d ? T[(size_t)i * d + c0 + c] : 0.f;
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+      for (int q = 0; q < RR; ++q) acc[r][q] = 0.f;
+    const float* pa[RR];
+    const float* pb[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {   // rows past n read row n - 1 (harmless, never stored)
+      pa[r] = tc + min(bi + 32 * r, n - 1) * (SM_CK + 1);
+      pb[r] = tc + min(bj + 32 * r, n - 1) * (SM_CK + 1);
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < SM_PAIRS; ++k) {
-      const float* a = tc + pi[k] * (SM_CK + 1);
-      const float* b = tc + pj[k] * (SM_CK + 1);
-      float s = acc[k];
-      if (c0 + SM_CK <= d) {
-#pragma unroll
-        for (int c = 0; c < SM_CK; ++c) s = fmaf(a[c], b[c], s);
-      } else {
-        for (int c = 0; c < d - c0; ++c) s = fmaf(a[c], b[c], s);
+    for (int c0 = 0; c0 < d; c0 += SM_CK) {
+      __syncthreads();
+      for (int e = t; e < n * SM_CK; e += SM_THREADS) {
+        const int i = e / SM_CK, c = e % SM_CK;
+        tc[i * (SM_CK + 1) + c] = c0 + c < d ? T[(size_t)i * d + c0 + c] : 0.f;   // zero-filled past d
       }
-      acc[k] = s;
-    }
-  }
+      __syncthreads();
+      if (mine) {
+#pragma unroll 8
+        for (int c = 0; c < SM_CK; ++c) {
+          float a[RR], b[RR];
 #pragma unroll
-  for (int k = 0; k < SM_PAIRS; ++k) {
-    const int p = t + k * SM_THREADS;
-    if (p < npairs) {
-      const float v = (rn[pi[k]] + rn[pj[k]]) - 2.f * acc[k];      // abstract_kernel.py:35
-      Dm[pi[k] * ldn + pj[k]] = v;
-      Dm[pj[k] * ldn + pi[k]] = v;
+          for (int r = 0; r < RR; ++r) { a[r] = pa[r][c]; b[r] = pb[r][c]; }
+#pragma unroll
+          for (int r = 0; r < RR; ++r)
+#pragma unroll
+            for (int q = 0; q < RR; ++q) acc[r][q] = fmaf(a[r], b[q], acc[r][q]);
+        }
+      }
     }
+    if (mine) {
+#pragma unroll
+      for (int r = 0; r < RR; ++r)
+#pragma unroll
+        for (int q = 0; q < RR; ++q) {
+          const int i = bi + 32 * r, j = bj + 32 * q;
+          if (i < n && j < n) Dm[i * ldn + j] = (rn[i] + rn[j]) - 2.f * acc[r][q];      // abstract_kernel.py:35
+        }
+    }
+  };
+  switch (R) {   // workgroup-uniform
+    case 1: distances(std::integral_constant<int, 1>()); break;
+    case 2: distances(std::integral_constant<int, 2>()); break;
+    case 3: distances(std::integral_constant<int, 3>()); break;
+    default: distances(std::integral_constant<int, 4>()); break;
   }
   // ---- exact median of the n^2 entries: 3-level radix select (11 / 11 / 10 bits), two targets for an even count ----
   const u32 total = (u32)n * (u32)n;
@@ -99,12 +108,13 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     s_prefix[0] = s_prefix[1] = 0u;
     s_div = 0u;
   }
+  __syncthreads();
   for (int level = 0; level < 3; ++level) {
     const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0), bits = level == 2 ? 10 : 11;
-    for (int b = t; b < 2 * STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;
-    __syncthreads();
     const u32 pa = s_prefix[0], pb = s_prefix[1];
     const bool two = s_div != 0u;
+    for (int b = t; b < (two ? 2 : 1) * STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;
+    __syncthreads();
     for (u32 e = t; e < total; e += SM_THREADS) {
       const u32 key = f32_key(Dm[(e / n) * ldn + (e % n)]);
       const u32 digit = (key >> shift) & ((1u << bits) - 1u);
@@ -114,9 +124,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     }
     __syncthreads();
     // locate each target's digit with a workgroup-wide prefix sum over the 2048 bins (two bins per thread); a
-    // single thread walking the bins took 65 us per level
-    for (int tg = 0; tg < 2; ++tg) {
-      const u32* h = hist + ((two && tg == 1) ? STEIN_HIST_BINS : 0);
+    // single thread walking the bins took 65 us per level.  While the targets share a prefix (almost always until the
+    // last level) one pass over the shared histogram serves both.
+    for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
+      const u32* h = hist + pass * STEIN_HIST_BINS;
       const u32 c0 = h[2 * t], c1 = h[2 * t + 1];
       u32 incl = c0 + c1;
 #pragma unroll
@@ -129,12 +140,17 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
       u32 base = 0u;
       for (int w = 0; w < wave; ++w) base += s_wsum[w];
       const u32 excl = base + incl - (c0 + c1);
-      const u32 rank = s_rank[tg];
+      const u32 rank0 = s_rank[0], rank1 = s_rank[1];
       __syncthreads();   // everybody has read s_rank / s_wsum before they change
-      if (rank >= excl && rank < excl + c0 + c1) {   // exactly one thread (the counts sum to more than rank)
-        const u32 b = rank < excl + c0 ? 2u * t : 2u * t + 1u;
-        s_prefix[tg] = (s_prefix[tg] << bits) | b;
-        s_rank[tg] = rank - (b & 1u ? excl + c0 : excl);
+#pragma unroll
+      for (int tg = 0; tg < 2; ++tg) {
+        if (two && tg != pass) continue;
+        const u32 rank = tg ? rank1 : rank0;
+        if (rank >= excl && rank < excl + c0 + c1) {   // exactly one thread (the counts sum to more than rank)
+          const u32 b = rank < excl + c0 ? 2u * t : 2u * t + 1u;
+          s_prefix[tg] = (s_prefix[tg] << bits) | b;
+          s_rank[tg] = rank - (b & 1u ? excl + c0 : excl);
+        }
       }
       __syncthreads();
     }
