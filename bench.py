@@ -4,16 +4,20 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one full particle update given the score matrix G (resident in HBM): row norms -> fp32-MFMA
-distance block -> exact median (3-level radix select) -> fused exp + fp32-MFMA contraction K.[G|theta]
--> phi, |phi|^2 -> clip + Adagrad apply (lr 1e-3, alpha 0.9).  Workload: BASELINE.json's roofline config
-"n=16384, d=256, fp32" (C3); with N ranks the same n is sharded by rows (strong scaling), one all-gather of
-theta and G rows, three histogram all-reduces and one scalar all-reduce per step over RCCL.
+A "step" is one full particle update given the score matrix G (resident in HBM): the fused C call
+stein_svgd_phi (row norms, operand scales and split planes -> distance pass on the 16-bit matrix cores with the
+speculative median window -> exact median -> fused exp + split-precision MFMA contraction K.[G|theta] -> phi,
+|phi|^2) followed by clip + Adagrad apply (lr 1e-3, alpha 0.9); particles move every step.  Workload:
+BASELINE.json's roofline config "n=16384, d=256, fp32" (C3, the configuration the north star's contraction
+target is quoted on); with N ranks the same n is sharded by rows (strong scaling): all-gathers of the theta and G
+rows, the median collectives (stein_amd/engine.py) and one scalar all-reduce per step over RCCL.  The secondary
+entry times C5 (n=131072) the same way.
 
 value = n * K / (max-over-ranks wall time of the K timed steps), bracketed by barrier + synchronize.
-roofline: k_phi_partial (the K.[G|theta] contraction), algorithmic flops 4*n_local*n*d per launch (2*n^2*d for
-K.G plus 2*n^2*d for K.theta), duration from HIP events recorded around each of its launches
-on the launching stream inside the timed region; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md).
+roofline: the K.[G|theta] contraction kernel (k_phi_x3fs, or k_phi_partial with STEIN_X3=0), algorithmic flops
+4*n_local*n*d per launch (2*n^2*d for K.G plus 2*n^2*d for K.theta), duration from HIP events
+recorded around each of its launches on the launching stream inside the timed region (by the library at one rank:
+STEIN_FLAG_TIMING); peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md).
 cpu_baseline: the NumPy oracle (a port: the reference's TF-1.12 kernel graph cannot run anywhere here) timed
 on the host on a bounded row block of the same workload.
 """
