@@ -37,6 +37,7 @@ PEAK_BF16_MFMA = 2.5e15        # same table: dense bf16 MFMA
 WORKLOADS = {
     "c3": dict(n=16384, d=256, name="C3 bayesian-logreg-shaped synthetic block n=16384 d=256 fp32 (roofline config)"),
     "c5": dict(n=131072, d=256, name="C5 n=131072 d=256 fp32, rows sharded over the ranks"),
+    "c2": dict(n=4096, d=128, bf16=True, name="C2 n=4096 d=128, theta and score fed to the kernels in bf16 (fp32 master copy)"),
     "c2f32": dict(n=4096, d=128, name="C2-shaped n=4096 d=128 run in fp32"),
     "c4": dict(n=8192, d=2001, name="C4 BNN-shaped n=8192 d=2001 (H=666) fp32"),
     "c1": dict(n=100, d=10, name="C1 n=100 d=10"),
@@ -86,8 +87,12 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
     n_local = n // world
     row0 = rank * n_local
     T64, G64, theta, G = make_inputs(n, d, row0, n_local, device, torch)
-    eng = SvgdEngine(n, d, device=device, group=group)
+    bf16 = bool(wl.get("bf16"))      # BASELINE config 2: the kernels see bf16 theta / score; theta's master copy stays fp32
+    eng = SvgdEngine(n, d, device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32)
     gd = AdagradGradientDescent(learning_rate=1e-3, alpha=0.9)
+    if bf16:
+        G = G.to(torch.bfloat16)
+    feed = (lambda: theta.to(torch.bfloat16)) if bf16 else (lambda: theta)
     clock = StageClock(torch)
 
     # Single rank: the fused C call (what SteinSampler.update_particles runs), with the library recording HIP events
@@ -100,7 +105,7 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
 
     def step(timed):
         if fused:
-            phi = eng.compute_phi(theta, G, timing=timed and clock_stages)
+            phi = eng.compute_phi(feed(), G, timing=timed and clock_stages)
             if timed and clock_stages:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -111,11 +116,11 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
                 gd.apply_(theta, phi, eng.sqnorm)
         elif timed and clock_stages:
             clock.begin_step()
-            phi = eng.compute_phi(theta, G, mark=clock.mark)
+            phi = eng.compute_phi(feed(), G, mark=clock.mark)
             gd.apply_(theta, phi, eng.sqnorm)
             clock.mark("apply_end")
         else:
-            phi = eng.compute_phi(theta, G, mark=(lambda s: None) if clock_stages else None)
+            phi = eng.compute_phi(feed(), G, mark=(lambda s: None) if clock_stages else None)
             gd.apply_(theta, phi, eng.sqnorm)
 
     for _ in range(warmup):
@@ -235,6 +240,9 @@ def main():
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
     value = n * args.steps / res["elapsed"]
+    global NPROD
+    if wl.get("bf16"):
+        NPROD = 1               # bf16 inputs: one bf16 product per pair
     k_ms = res["stages"].get("contract")
     flops = 4.0 * nl * n * d
     achieved = flops / (k_ms * 1e-3) if k_ms else None
@@ -249,7 +257,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16" if wl.get("bf16") else "f32",
         "data": "synthetic",
         "config": {"workload": wl["name"], "n": n, "d": d, "rows_per_rank": nl,
                    "optimizer": "adagrad lr=1e-3 alpha=0.9",
@@ -272,7 +280,7 @@ def main():
             "frac_of_executed_dtype_peak": ((NPROD * achieved / PEAK_BF16_MFMA) if res["x3"] else achieved / PEAK_FP32_MFMA)
             if achieved else None,
         },
-        "gemm_path": ("split fp16 x 2 (3 products)" if NPROD == 3 else "split bf16 x 3 (6 products)") if res["x3"] else "fp32 mfma",
+        "gemm_path": ({1: "bf16 inputs (1 product)", 3: "split fp16 x 2 (3 products)", 6: "split bf16 x 3 (6 products)"}[NPROD]) if res["x3"] else "fp32 mfma",
         "stage_ms": {k: round(v, 4) for k, v in res["stages"].items()},
         "full_step_tflops": 6.0 * nl * n * d / (ms_per_step * 1e-3) / 1e12,
         "finite": res["finite"],
