@@ -192,10 +192,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // radix select: histogram pass, resolve (keys, state and hist_add are defined above k_distance)
 // ------------------------------------------------------------------------------------------------
+// ---- chained form of the radix select (fused call only): the histogram passes resolve the earlier levels
+// themselves, so the fused call launches no k_resolve between them (and nothing at all between them matters when the
+// speculative window hit: every launch is a few microseconds even when it returns at once).
+// Block-wide (256 threads): the select state after `levels` resolved levels, computed from the INITIAL state in
+// *st (ranks set by k_median_init, prefixes 0 -- nothing writes *st until k_resolve_all) and the global histograms.
+struct ChainState { u32 prefix[2]; u64 rank[2]; bool two; };
+__device__ __forceinline__ ChainState chain_resolve(const u64* __restrict__ hist_all, int levels, const SelState* st) {
+  __shared__ u64 c_part[256];
+  __shared__ u32 c_bin[2];
+  __shared__ u64 c_rest[2];
+  const int t = threadIdx.x;
+  ChainState cs;
+  cs.prefix[0] = cs.prefix[1] = 0u;
+  cs.rank[0] = st->rank[0]; cs.rank[1] = st->rank[1];
+  cs.two = false;
+  for (int level = 0; level < levels; ++level) {
+    const int bits = level == 2 ? 10 : 11;
+    const u64* hl = hist_all + (size_t)level * 2 * STEIN_HIST_BINS;
+    for (int tg = 0; tg < 2; ++tg) {
+      const u64* src = hl + ((cs.two && tg == 1) ? STEIN_HIST_BINS : 0);
+      u64 mine[8], sum = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { mine[k] = src[t * 8 + k]; sum += mine[k]; }
+      c_part[t] = sum;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
+        u64 v = 0;
+        if (t >= o) v = c_part[t - o];
+        __syncthreads();
+        c_part[t] += v;
+        __syncthreads();
+      }
+      const u64 excl = c_part[t] - sum, rank = cs.rank[tg];
+      if (t == 255 && rank >= c_part[255]) { c_bin[tg] = (u32)((1 << bits) - 1); c_rest[tg] = 0; }   // cannot happen: counts cover the rank
+      if (rank >= excl && rank < excl + sum) {
+        u64 cum = excl;
+        int k = 0;
+        while (k < 7 && cum + mine[k] <= rank) cum += mine[k++];
+        c_bin[tg] = (u32)(t * 8 + k);
+        c_rest[tg] = rank - cum;
+      }
+      __syncthreads();
+      cs.prefix[tg] = (cs.prefix[tg] << bits) | c_bin[tg];
+      cs.rank[tg] = c_rest[tg];
+      __syncthreads();
+    }
+    cs.two = cs.prefix[0] != cs.prefix[1];
+  }
+  return cs;
+}
+
 // SYM (square symmetric block): only columns >= row are read; an off-diagonal entry counts twice.
 // Level 0 sees every value and a handful of bins hold them all -> wave-merged adds.  Levels 1-2 only see the
 // values inside the selected bin, spread over up to 2048 digits -> plain LDS atomics are cheaper.
-template <int LEVEL, bool SYM>
+// CHAIN: `hist` points at level 0 of ALL levels and the block resolves the earlier levels itself (chain_resolve);
+// otherwise `hist` is this level's histogram and *st holds the state left by k_resolve.
+template <int LEVEL, bool SYM, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
                                               const SelState* __restrict__ st, u64* __restrict__ hist,
                                               const u32* __restrict__ skip) {
@@ -204,8 +257,16 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
   __syncthreads();
 
-  const u32 pa = st->prefix[0], pb = st->prefix[1];
-  const bool two = st->diverged != 0u;
+  u32 pa, pb;
+  bool two;
+  if (CHAIN) {
+    const ChainState cs = chain_resolve(hist, LEVEL, st);
+    pa = cs.prefix[0]; pb = cs.prefix[1]; two = cs.two;
+    hist += (size_t)LEVEL * 2 * STEIN_HIST_BINS;
+  } else {
+    pa = st->prefix[0]; pb = st->prefix[1];
+    two = st->diverged != 0u;
+  }
   const int lane = threadIdx.x & 63;
   // one unit = one [128][32] tile of the tile-major block (16 KB, 4 x 16 B per thread); SYM skips the tiles that lie
   // entirely below the diagonal
@@ -332,6 +393,8 @@ __global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp
   sp->reserved = 0ull; sp->total = total;
 }
 
+__device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* sp);   // below
+
 // All 256 bins of an LDS histogram -> the bin holding 0-based rank `rank` and the rank inside it; *bin = 256 when the
 // rank lies past the last bin.  Called by the whole workgroup (>= 256 threads); `scan` is 256 words of LDS scratch.
 __device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u32* bin, u32* rest) {
@@ -357,7 +420,7 @@ __device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u
 // Entry = key << 2 | weight, offset o = key - lo_key < 65536: pass 1 histograms o >> 8, pass 2 the low byte of the
 // entries that share each target's high byte.
 __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* sp, const u64* __restrict__ slots,
-                                                      float ln_n, float* h2_out) {
+                                                      float ln_n, float* h2_out, int update) {
   const u64* __restrict__ buf = slots + SPEC_SLOTS * 8;
   __shared__ u32 h1[256], h2a[256], h2b[256], scan[256];
   __shared__ u32 sel[8];   // [0,1] high bytes, [2,3] ranks inside them, [4,5] low bytes, [6,7] scratch
@@ -401,6 +464,7 @@ __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* s
     if (h2_out) *h2_out = h2;
     sp->hit = 1u;
     sp->skip_l0 = 1u;
+    if (update) spec_update_dev(st, sp);   // fused call: no separate k_spec_update launch
   }
 }
 
@@ -483,9 +547,8 @@ __global__ __launch_bounds__(1024) void k_spec_pick(SelState* st, SpecState* sp,
   }
 }
 
-// after the median is final (window or radix passes): predict the next one and size its window
-__global__ void k_spec_update(const SelState* st, SpecState* sp) {
-  if (threadIdx.x || blockIdx.x) return;
+// after the median is final (window or radix passes): predict the next one and size its window (one thread)
+__device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* sp) {
   const u32 key = f32_key(st->lo);
   const bool had_window = sp->width != 0u;
   u32 hw = 4096u, next = key;
@@ -507,6 +570,29 @@ __global__ void k_spec_update(const SelState* st, SpecState* sp) {
   sp->last_key = key;
   sp->center = next;
   sp->halfwidth = hw > SPEC_HW_MAX ? SPEC_HW_MAX : hw;
+}
+__global__ void k_spec_update(const SelState* st, SpecState* sp) {
+  if (threadIdx.x || blockIdx.x) return;
+  spec_update_dev(st, sp);
+}
+
+// last kernel of the chained radix select (fused call): all three resolves, the median / bandwidth, the predictor update
+__global__ __launch_bounds__(256) void k_resolve_all(const u64* __restrict__ hist_all, SelState* st, SpecState* sp,
+                                                     float ln_n, float* h2_out) {
+  if (sp->hit) return;   // the window produced the median; k_spec_select updated the predictor
+  const ChainState cs = chain_resolve(hist_all, STEIN_HIST_LEVELS, st);
+  if (threadIdx.x == 0) {
+    st->prefix[0] = cs.prefix[0]; st->prefix[1] = cs.prefix[1];
+    st->rank[0] = cs.rank[0]; st->rank[1] = cs.rank[1];
+    st->diverged = cs.two ? 1u : 0u;
+    const float lo = key_f32(cs.prefix[0]), hi = key_f32(cs.prefix[1]);
+    const float med = st->even ? 0.5f * (lo + hi) : lo;
+    const float bw = sqrtf(med / ln_n);      // abstract_kernel.py:40
+    const float h2 = bw * bw;                // squared_exponential_kernel.py:22 squares it again
+    st->lo = lo; st->hi = hi; st->median = med; st->h2 = h2;
+    if (h2_out) *h2_out = h2;
+    spec_update_dev(st, sp);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -939,29 +1025,34 @@ extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total,
 }
 
 template <int LEVEL>
-static void launch_hist(bool sym, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
+static void launch_hist(bool sym, bool chain, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
                         const SelState* st, u64* h, const u32* skip) {
-  if (sym)
+  if (sym && chain)
+    hipLaunchKernelGGL((k_hist<LEVEL, true, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
+  else if (sym)
     hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
   else
     hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
 }
 
+// chain (fused symmetric call only): the pass resolves the earlier levels itself, `hist` is the base of all levels
 static int hist_pass_impl(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
-                          const void* select_state, void* hist, int flags, void* stream, const u32* skip) {
+                          const void* select_state, void* hist, int flags, void* stream, const u32* skip,
+                          bool chain = false) {
   if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
   if (ld_dist < n || (ld_dist & 31) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape (ld_dist must be a multiple of 32)");
   const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
   if (sym && n_local != n) return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs a square block");
+  if (chain && !sym) return fail(STEIN_E_BADARG, "the chained select is the fused symmetric call's");
   const long units = ((n_local + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);   // [128][32] tiles
   const int blocks = (int)(units < 2048 ? units : 2048);
-  u64* h = (u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
+  u64* h = (u64*)hist + (chain ? 0 : (size_t)level * 2 * STEIN_HIST_BINS);
   const SelState* st = (const SelState*)select_state;
   hipStream_t s = (hipStream_t)stream;
-  if (level == 0) launch_hist<0>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
-  else if (level == 1) launch_hist<1>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
-  else launch_hist<2>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  if (level == 0) launch_hist<0>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  else if (level == 1) launch_hist<1>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  else launch_hist<2>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
   LAUNCH_CHECK("k_hist");
   return STEIN_OK;
 }
@@ -1218,16 +1309,17 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   // the window either yields the median now (spec->hit) or the radix-select passes below run; each of them
   // checks the flag on the device, so nothing here waits for the host
   hipLaunchKernelGGL(k_spec_select, dim3(1), dim3(1024), 0, s, (SelState*)sel, spec, spec_buf,
-                     (float)log((double)n), h2_out);
+                     (float)log((double)n), h2_out, 1);
   LAUNCH_CHECK("k_spec_select");
-  for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv) {
-    // level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it)
-    if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit)))
+  // chained radix select: three passes that resolve the earlier levels themselves + one kernel for the rest.
+  // Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
+  for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv)
+    if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit,
+                             true)))
       return rc;
-    if ((rc = resolve_impl(hist, lv, n, sel, h2_out, nullptr, stream, &spec->hit))) return rc;
-  }
-  hipLaunchKernelGGL(k_spec_update, dim3(1), dim3(64), 0, s, (const SelState*)sel, spec);
-  LAUNCH_CHECK("k_spec_update");
+  hipLaunchKernelGGL(k_resolve_all, dim3(1), dim3(256), 0, s, (const u64*)hist, (SelState*)sel, spec,
+                     (float)log((double)n), h2_out);
+  LAUNCH_CHECK("k_resolve_all");
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;
   STEIN_TSTAMP(STEIN_T_CONTRACT);
   if ((rc = stein_contract_partial(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, planes,
