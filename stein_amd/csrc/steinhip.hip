@@ -398,20 +398,26 @@ __device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* s
 // All 256 bins of an LDS histogram -> the bin holding 0-based rank `rank` and the rank inside it; *bin = 256 when the
 // rank lies past the last bin.  Called by the whole workgroup (>= 256 threads); `scan` is 256 words of LDS scratch.
 __device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u32* bin, u32* rest) {
-  const int t = threadIdx.x;
-  if (t < 256) scan[t] = h[t];
+  // the first four waves scan 64 bins each with shuffles; `scan[0..3]` carries the wave totals (3 barriers in all)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  u32 c = 0u, incl = 0u;
+  if (t < 256) {
+    c = h[t];
+    incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const u32 v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) scan[wave] = incl;
+  }
   if (t == 0) *bin = 256u;
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scan
-    u32 v = 0u;
-    if (t < 256 && t >= o) v = scan[t - o];
-    __syncthreads();
-    if (t < 256) scan[t] += v;
-    __syncthreads();
-  }
   if (t < 256) {
-    const u32 incl = scan[t], excl = incl - h[t];
-    if (excl <= rank && rank < incl) { *bin = (u32)t; *rest = rank - excl; }
+    u32 base = 0u;
+    for (int w = 0; w < wave; ++w) base += scan[w];
+    const u32 excl = base + incl - c;
+    if (excl <= rank && rank < excl + c) { *bin = (u32)t; *rest = rank - excl; }
   }
   __syncthreads();
 }
