@@ -153,7 +153,8 @@ class SvgdEngine:
         # small=False: the fused call never takes the one-kernel path for n <= 128 (tests of the tiled kernels)
         self.flags = (_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED)
         # several ranks: use the speculative median window (one 512 KB all-reduce and a hit-flag read-back per step
-        # instead of two passes over the local distance block) when the block is large enough for that to pay;
+        # instead of two passes over the local distance block) when the block is large enough for that to pay
+        # (>= 2^27 entries: the two passes then cost more than the table all-reduce plus the read-back stall);
         # STEIN_DIST_WINDOW=0/1 forces it
         self.dist_window = False
         self.window_hit = None
@@ -183,7 +184,7 @@ class SvgdEngine:
         self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
         if self.world > 1 and hasattr(self.stages, "spec_begin"):
             env = os.environ.get("STEIN_DIST_WINDOW", "")
-            self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 28))
+            self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 27))
         if self.world > 1:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
