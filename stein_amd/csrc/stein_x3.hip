@@ -453,13 +453,18 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
 //                            B fragments (V) by one coalesced 1 KB global load each, issued one k tile ahead right
 //                            after the registers' last use; 48 MFMAs per k tile and wave
 //   Every SIMD holds one producer and two consumers.  V never touches LDS and is fetched exactly once per workgroup
-//   (no two waves share a B fragment).  One barrier per pipeline stage (two k tiles) hands the P stages over.
+//   (no two waves share a B fragment).  One barrier per pipeline stage (four k tiles; two for the three-plane kind)
+//   hands the P stages over.
 //   Column space: the 128-column blocks of [G | theta] (each matrix padded to dc = roundup(d, 128)) are paired up,
 //   block cb covers pair (2cb, 2cb+1); consumer wave cw takes half cw >> 2, 32-column block cw & 3.
 // ------------------------------------------------------------------------------------------------
 constexpr int FS_THREADS = 768;
-constexpr int FS_KT = 2;                   // k tiles per pipeline stage (even: tile parity picks the register set)
-constexpr int FS_STAGE = FS_KT * XOPER;    // P planes, 128 rows x 2 k tiles: 49152 B per pipeline stage (2 stages)
+// k tiles per pipeline stage (even: tile parity picks the register set) and the LDS of one k tile (NP planes, packed)
+template <int NP> struct FsGeom {
+  static constexpr int KT = NP == 3 ? 2 : 4;          // 2 stages x KT x NP x 8 KB: 128 KB (NP 2), 96 KB (NP 3), 64 KB (NP 1)
+  static constexpr int KTB = NP * XPLANE;
+  static constexpr int STAGE = KT * KTB;
+};
 
 template <int NP>
 __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict__ D, long ldD,
@@ -469,6 +474,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
                                                          float* __restrict__ RS, int n, int d, int n_local,
                                                          int tiles_m, int cblocks, int split, int jchunk,
                                                          const float* __restrict__ sc, int dc) {
+  constexpr int FS_KT = FsGeom<NP>::KT, FS_KTB = FsGeom<NP>::KTB, FS_STAGE = FsGeom<NP>::STAGE;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FS_STAGE];
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -544,20 +550,23 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
     u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
-    // A pipeline stage holds FS_KT = 2 consecutive k tiles, so the workgroup synchronises once per two tiles.  Tile
+    // A pipeline stage holds FS_KT consecutive k tiles, so the workgroup synchronises once per FS_KT tiles.  Tile
     // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
     const int nstage = (ntile + FS_KT - 1) / FS_KT;
     if (ntile > 0) issue_loads(jt(0), rdX);
     if (ntile > 1) issue_loads(jt(1), rdY);
     auto produce_stage = [&](int st, unsigned char* buf) {
       const int tile = st * FS_KT;
-      if (tile < ntile) {
-        produce(jt(tile), buf, rdX);
-        if (tile + 2 < ntile) issue_loads(jt(tile + 2), rdX);
-      }
-      if (tile + 1 < ntile) {
-        produce(jt(tile + 1), buf + XOPER, rdY);
-        if (tile + 3 < ntile) issue_loads(jt(tile + 3), rdY);
+#pragma unroll
+      for (int u = 0; u < FS_KT; u += 2) {
+        if (tile + u < ntile) {
+          produce(jt(tile + u), buf + u * FS_KTB, rdX);
+          if (tile + u + 2 < ntile) issue_loads(jt(tile + u + 2), rdX);
+        }
+        if (tile + u + 1 < ntile) {
+          produce(jt(tile + u + 1), buf + (u + 1) * FS_KTB, rdY);
+          if (tile + u + 3 < ntile) issue_loads(jt(tile + u + 3), rdY);
+        }
       }
     };
     produce_stage(0, smem);
@@ -648,13 +657,17 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #else
 #define BWAIT() do {} while (0)
 #endif
-      BWAIT();
-      if (tile + 1 < ntile) load_b(tile + 1, bY);
-      mma_tile(As, bX);
-      if (tile + 1 < ntile) {
+#pragma unroll
+      for (int u = 0; u < FS_KT; u += 2) {
+        if (tile + u >= ntile) break;
         BWAIT();
-        if (tile + 2 < ntile) load_b(tile + 2, bX);
-        mma_tile(As + XOPER, bY);
+        if (tile + u + 1 < ntile) load_b(tile + u + 1, bY);
+        mma_tile(As + u * FS_KTB, bX);
+        if (tile + u + 1 < ntile) {
+          BWAIT();
+          if (tile + u + 2 < ntile) load_b(tile + u + 2, bX);
+          mma_tile(As + (u + 1) * FS_KTB, bY);
+        }
       }
       STAMP(3);   // consumer: fragment reads + MFMAs
       __syncthreads();
