@@ -10,9 +10,12 @@ eng = SvgdEngine(n, d, device="cuda", x3=True)
 eng.compute_phi(T, G); torch.cuda.synchronize()
 buf = (ctypes.c_uint64 * 8)()
 lib.stein_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
-lib.stein_debug_stamps(buf, 1)
-eng.compute_phi(T, G); torch.cuda.synchronize()
-lib.stein_debug_stamps(buf, 0)
+def mark(label):        # the staged calls: reset the counters right before the contraction, read them right after
+    if label == "contract":
+        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1)
+    elif label == "finish":
+        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0)
+eng.compute_phi(T, G, mark=mark); torch.cuda.synchronize()
 v = np.array(list(buf), dtype=np.float64)
 nb = v[7]
 jt = (n + 31) // 32

@@ -494,9 +494,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     const int pt = t;
     const int lr = pt >> 3, lc = (pt & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    // two register sets (X for even tiles, Y for odd): the loads of tile t+2 are issued as soon as tile t has been
-    // turned into LDS data, so they fly during the whole production of tile t+1 and the barrier wait behind it
-    float4 rdX[4], rdY[4];
+    // PD register sets (tile index mod PD picks the set): the loads of tile t + PD are issued as soon as tile t has been
+    // turned into LDS data.  D streams from HBM (never re-used), so the loads need several tiles of lead
+    constexpr int PD = FS_KT;   // 4 (2 for the three-plane kind); FS_KT % PD == 0 keeps the set index static
+    float4 rd[PD][4];
     u32 doff[4];
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
     constexpr float pofs = (float)SplitTraits<NP>::pexp;        // P carries 2^pexp (undone by the out-scales)
@@ -553,19 +554,16 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // A pipeline stage holds FS_KT consecutive k tiles, so the workgroup synchronises once per FS_KT tiles.  Tile
     // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
     const int nstage = (ntile + FS_KT - 1) / FS_KT;
-    if (ntile > 0) issue_loads(jt(0), rdX);
-    if (ntile > 1) issue_loads(jt(1), rdY);
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (u < ntile) issue_loads(jt(u), rd[u]);
     auto produce_stage = [&](int st, unsigned char* buf) {
       const int tile = st * FS_KT;
 #pragma unroll
-      for (int u = 0; u < FS_KT; u += 2) {
+      for (int u = 0; u < FS_KT; ++u) {
         if (tile + u < ntile) {
-          produce(jt(tile + u), buf + u * FS_KTB, rdX);
-          if (tile + u + 2 < ntile) issue_loads(jt(tile + u + 2), rdX);
-        }
-        if (tile + u + 1 < ntile) {
-          produce(jt(tile + u + 1), buf + (u + 1) * FS_KTB, rdY);
-          if (tile + u + 3 < ntile) issue_loads(jt(tile + u + 3), rdY);
+          produce(jt(tile + u), buf + u * FS_KTB, rd[u % PD]);
+          if (tile + u + PD < ntile) issue_loads(jt(tile + u + PD), rd[u % PD]);
         }
       }
     };
