@@ -128,6 +128,16 @@ struct SpecState {
   u64 pad;
 };
 static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
+// Third 64-byte block of the SELECT section (fused call only): "last workgroup out" tickets that let a kernel's last
+// workgroup do what used to be a one-workgroup follow-up launch (scales after the column maxima, the final resolve after
+// the level-2 histogram).  Zeroed by the fused call's first kernel; each ticket also resets itself.  (The |phi|^2 sum
+// after k_phi_finish's partials was tried the same way: its 1024 workgroups waiting on their stores cost more than the
+// launch saved.)
+struct FuseState {
+  u32 done_colmax, done_hist;
+  u32 pad[14];
+};
+static_assert(sizeof(FuseState) == 64, "FuseState must stay 64 bytes");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;
 constexpr u32 SPEC_QCAP = 1016;          // per-workgroup LDS queue (entries of 8 bytes; shares its LDS with the histogram)
 constexpr u32 SPEC_CAP = (1u << 21) - 2048u;   // global buffer capacity (entries); the 16 MB section starts with
@@ -149,6 +159,28 @@ __device__ __forceinline__ u32 f32_key(float x) {  // monotone: a < b  <=>  key(
 __device__ __forceinline__ float key_f32(u32 k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+
+// "Last workgroup out".  Call once per workgroup, by every thread, after the workgroup's results have been issued: true
+// in exactly one workgroup, the last to arrive.  The 8 XCDs have private L2s, so a device-wide fence per workgroup would
+// write back and invalidate a whole L2 every time (measured: 3x the kernel time).  Instead the results that cross
+// workgroups must be WRITTEN with device-scope atomics (atomicAdd / atomicMax) and READ with load_fresh --
+// those go to the coherent level themselves -- and only the order matters here: every wave waits until its outstanding
+// memory operations have been acknowledged (s_waitcnt vmcnt(0); a workgroup barrier alone does not) before thread 0
+// draws the ticket.  The counter is left at zero.
+__device__ __forceinline__ bool last_workgroup_out(u32* counter, u32 nblocks) {
+  __shared__ u32 s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    const u32 last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u ? 1u : 0u;
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0u;
+}
+__device__ __forceinline__ u64 load_fresh(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 load_fresh(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Add `valid` lanes' digits to an LDS histogram.  Distances cluster (a handful of top-level bins hold
 // everything), so the wave first merges lanes that share the leader's digit into one atomic, twice,

@@ -6,7 +6,7 @@
 // STEIN_SPLIT_KIND=b3); STEIN_BF16: bf16 inputs, one plane, one product
 int stein_x3_kind(int dtype);   // 1, 2 or 3
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d, const SteinLayout& L,
-                   char* planes, hipStream_t stream);
+                   char* planes, hipStream_t stream, u32* fuse_done = nullptr);
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                       int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
                       hipStream_t stream, SpecState* spec = nullptr, u64* spec_buf = nullptr);

@@ -161,38 +161,19 @@ __device__ __forceinline__ int scale_exp(u32 maxbits, int lim) {
   return sft < -lim ? -lim : (sft > lim ? lim : sft);
 }
 
-// column maxima of |X| [n][d] as bit patterns (non-negative floats order like unsigned integers)
-// blockIdx.z = 0: X0 -> cmax[0, dc), 1: X1 -> cmax[dc, 2 dc)
-template <typename TIN>
-__global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
-                                                u32* __restrict__ cmax0, int dc, int zbase) {
-  const int z = blockIdx.z + zbase;
-  const TIN* __restrict__ X = z ? X1 : X0;
-  u32* __restrict__ cmax = cmax0 + (z ? dc : 0);
-  __shared__ u32 red[4][64];
-  const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
-  const int col = blockIdx.x * 64 + cx;
-  u32 m = 0u;
-  if (col < d)
-    for (long r = (long)blockIdx.y * 4 + ry; r < n; r += (long)gridDim.y * 4) m = max(m, abs_bits(X[(size_t)r * d + col]));
-  red[ry][cx] = m;
-  __syncthreads();
-  if (ry == 0 && col < d) atomicMax(&cmax[col], max(max(red[0][cx], red[1][cx]), max(red[2][cx], red[3][cx])));
-}
-
-// one workgroup: maxima -> the scales area (see the header).  enable = 0 writes the neutral scales.
-__global__ __launch_bounds__(256) void k_make_scales(const u32* __restrict__ cmax, int dc, float* __restrict__ sc, int pexp,
-                                                     int enable) {
-  __shared__ u32 red[256];
+// maxima -> the scales area (see the header), by one workgroup of 256 threads.  enable = 0 writes the neutral scales.
+__device__ __forceinline__ void make_scales_body(const u32* cmax, int dc, float* __restrict__ sc, int pexp, int enable,
+                                                 u32* red) {
   const int t = threadIdx.x;
   u32 m = 0u;
   for (int c = t; c < dc; c += 256) {
-    const int sg = enable ? scale_exp(cmax[c], 100) : 0, st = enable ? scale_exp(cmax[dc + c], 100) : 0;
+    const u32 mg = load_fresh(cmax + c), mt = load_fresh(cmax + dc + c);
+    const int sg = enable ? scale_exp(mg, 100) : 0, st = enable ? scale_exp(mt, 100) : 0;
     sc[c] = pow2i(sg);
     sc[dc + c] = pow2i(st);
     sc[2 * dc + c] = pow2i(-sg - pexp);
     sc[3 * dc + c] = pow2i(-st - pexp);
-    m = max(m, cmax[dc + c]);
+    m = max(m, mt);
   }
   red[t] = m;
   __syncthreads();
@@ -206,6 +187,37 @@ __global__ __launch_bounds__(256) void k_make_scales(const u32* __restrict__ cma
     sc[4 * dc + 1] = pow2i(1 - 2 * sa);
     sc[4 * dc + 2] = pow2i(-pexp);
   }
+}
+
+// column maxima of |X| [n][d] as bit patterns (non-negative floats order like unsigned integers)
+// blockIdx.z = 0: X0 -> cmax[0, dc), 1: X1 -> cmax[dc, 2 dc)
+// done != NULL (fused call: both matrices given, counter zeroed beforehand): the last workgroup to finish also turns
+// the maxima into the scales, which saves the k_make_scales launch.
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
+                                                u32* __restrict__ cmax0, int dc, int zbase, float* __restrict__ sc,
+                                                int pexp, u32* done) {
+  const int z = blockIdx.z + zbase;
+  const TIN* __restrict__ X = z ? X1 : X0;
+  u32* __restrict__ cmax = cmax0 + (z ? dc : 0);
+  __shared__ u32 red[4][64];
+  const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  u32 m = 0u;
+  if (col < d)
+    for (long r = (long)blockIdx.y * 4 + ry; r < n; r += (long)gridDim.y * 4) m = max(m, abs_bits(X[(size_t)r * d + col]));
+  red[ry][cx] = m;
+  __syncthreads();
+  if (ry == 0 && col < d) atomicMax(&cmax[col], max(max(red[0][cx], red[1][cx]), max(red[2][cx], red[3][cx])));
+  if (done && last_workgroup_out(done, gridDim.x * gridDim.y * gridDim.z))
+    make_scales_body(cmax0, dc, sc, pexp, 1, &red[0][0]);
+}
+
+// one workgroup: maxima -> the scales area
+__global__ __launch_bounds__(256) void k_make_scales(const u32* __restrict__ cmax, int dc, float* __restrict__ sc, int pexp,
+                                                     int enable) {
+  __shared__ u32 red[256];
+  make_scales_body(cmax, dc, sc, pexp, enable, red);
 }
 
 // One 64x64 tile of X [n][d] per workgroup.
@@ -725,8 +737,10 @@ static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score,
                      (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc, zbase);
 }
 
+// fuse_done != NULL (fused call): the caller has zeroed the column maxima and the ticket, both matrices are given, and
+// the column-maxima kernel's last workgroup writes the scales itself
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
-                   const SteinLayout& L, char* planes, hipStream_t stream) {
+                   const SteinLayout& L, char* planes, hipStream_t stream, u32* fuse_done) {
   u16* T3 = reinterpret_cast<u16*>(planes + L.x3_t3);
   u16* Tt3 = reinterpret_cast<u16*>(planes + L.x3_tt3);
   u16* Gt3 = reinterpret_cast<u16*>(planes + L.x3_gt3);
@@ -734,20 +748,26 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
   const int dc = (int)L.x3_dc;
   u32* cmax = reinterpret_cast<u32*>(sc + 4 * dc + 4);
   const int kind = split_kind(dtype);
+  if (fuse_done && !(theta_all && score_all)) fuse_done = nullptr;
   if (kind == 2) {   // column maxima of the matrices given (cmax = [score | theta]); the other half keeps its values
     const int zbase = score_all ? 0 : 1;
     const unsigned nz = (score_all ? 1u : 0u) + (theta_all ? 1u : 0u);
-    HIP_TRY(hipMemsetAsync(cmax + (size_t)zbase * dc, 0, (size_t)nz * dc * sizeof(u32), stream));
+    if (!fuse_done) HIP_TRY(hipMemsetAsync(cmax + (size_t)zbase * dc, 0, (size_t)nz * dc * sizeof(u32), stream));
     int gy = (int)((n + 63) / 64);
     if (gy > 256) gy = 256;
     const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, nz);
+    // a ticket per workgroup is one more same-address atomic each: beyond a few hundred workgroups the separate
+    // k_make_scales launch is the cheaper way
+    if ((long)grid.x * grid.y * grid.z > 512) fuse_done = nullptr;
     hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (const float*)theta_all,
-                       (int)n, (int)d, cmax, dc, zbase);
+                       (int)n, (int)d, cmax, dc, zbase, sc, PEXP_H2, fuse_done);
     LAUNCH_CHECK("k_colmax");
   }
-  hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(256), 0, stream, cmax, dc, sc, kind == 2 ? PEXP_H2 : 0,
-                     kind == 2 ? 1 : 0);
-  LAUNCH_CHECK("k_make_scales");
+  if (kind != 2 || !fuse_done) {
+    hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(256), 0, stream, cmax, dc, sc, kind == 2 ? PEXP_H2 : 0,
+                       kind == 2 ? 1 : 0);
+    LAUNCH_CHECK("k_make_scales");
+  }
   if (kind == 1) launch_split<u16, 1>(stream, (const u16*)theta_all, (const u16*)score_all, n, d, L, T3, Tt3, Gt3, sc);
   else if (kind == 2) launch_split<float, 2>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
   else launch_split<float, 3>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);

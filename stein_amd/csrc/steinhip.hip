@@ -196,9 +196,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
 // themselves, so the fused call launches no k_resolve between them (and nothing at all between them matters when the
 // speculative window hit: every launch is a few microseconds even when it returns at once).
 // Block-wide (256 threads): the select state after `levels` resolved levels, computed from the INITIAL state in
-// *st (ranks set by k_median_init, prefixes 0 -- nothing writes *st until k_resolve_all) and the global histograms.
+// *st (ranks set by k_median_init, prefixes 0 -- nothing writes *st until resolve_all_body) and the global histograms.
 struct ChainState { u32 prefix[2]; u64 rank[2]; bool two; };
-__device__ __forceinline__ ChainState chain_resolve(const u64* __restrict__ hist_all, int levels, const SelState* st) {
+__device__ __forceinline__ ChainState chain_resolve(const u64* hist_all, int levels, const SelState* st) {
   __shared__ u64 c_part[256];
   __shared__ u32 c_bin[2];
   __shared__ u64 c_rest[2];
@@ -214,7 +214,7 @@ __device__ __forceinline__ ChainState chain_resolve(const u64* __restrict__ hist
       const u64* src = hl + ((cs.two && tg == 1) ? STEIN_HIST_BINS : 0);
       u64 mine[8], sum = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { mine[k] = src[t * 8 + k]; sum += mine[k]; }
+      for (int k = 0; k < 8; ++k) { mine[k] = load_fresh(src + t * 8 + k); sum += mine[k]; }   // may follow this kernel's own atomics
       c_part[t] = sum;
       __syncthreads();
       for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
@@ -248,11 +248,23 @@ __device__ __forceinline__ ChainState chain_resolve(const u64* __restrict__ hist
 // values inside the selected bin, spread over up to 2048 digits -> plain LDS atomics are cheaper.
 // CHAIN: `hist` points at level 0 of ALL levels and the block resolves the earlier levels itself (chain_resolve);
 // otherwise `hist` is this level's histogram and *st holds the state left by k_resolve.
+// fin.done != NULL (last level of the chained select): the last workgroup to finish also resolves all levels, writes the
+// median / bandwidth and updates the window predictor.
+struct HistFinal {
+  SelState* st;
+  SpecState* sp;
+  float* h2_out;
+  u32* done;
+  float ln_n;
+};
+__device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out);   // below
+
 template <int LEVEL, bool SYM, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
-                                              const SelState* __restrict__ st, u64* __restrict__ hist,
-                                              const u32* __restrict__ skip) {
+                                              const SelState* st, u64* hist, const u32* __restrict__ skip,
+                                              HistFinal fin) {
   if (skip && *skip) return;   // the speculative window already produced this step's median
+  u64* const hist_all = hist;
   __shared__ u32 h[2 * STEIN_HIST_BINS];
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
   __syncthreads();
@@ -310,6 +322,9 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
   __syncthreads();
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
     if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
+  if (CHAIN && LEVEL == STEIN_HIST_LEVELS - 1) {
+    if (fin.done && last_workgroup_out(fin.done, gridDim.x)) resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
+  }
 }
 
 // one wave; hist points at this level's [2][STEIN_HIST_BINS] counters (already summed over ranks)
@@ -365,9 +380,9 @@ __global__ __launch_bounds__(64) void k_resolve(const u64* __restrict__ hist, in
 // speculative median window (SpecState in stein_common.h): begin / select / update, one launch each per step
 // ------------------------------------------------------------------------------------------------
 // fused-call prologue: k_sel_init + the window set-up + zeroing of the histograms and of the "below" slots
-__global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp, u64 total, u64* __restrict__ hist,
-                                                     u64* __restrict__ slots) {
-  const int gt = blockIdx.x * 256 + threadIdx.x, gn = gridDim.x * 256;
+// (gt of gn threads share the zeroing; thread 0 sets the states up)
+__device__ __forceinline__ void median_init_body(int gt, int gn, SelState* st, SpecState* sp, u64 total,
+                                                 u64* __restrict__ hist, u64* __restrict__ slots) {
   for (int i = gt; i < STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS; i += gn) hist[i] = 0ull;
   for (int i = gt; i < (int)SPEC_SLOTS * 8; i += gn) slots[i] = 0ull;
   if (gt) return;
@@ -391,6 +406,41 @@ __global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp
   sp->count = 0u; sp->overflow = 0u; sp->hit = 0u;
   sp->skip_l0 = sp->width == 0u ? 1u : 0u;   // no window: the distance epilogue takes the level-0 histogram itself
   sp->reserved = 0ull; sp->total = total;
+}
+
+__global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp, u64 total, u64* __restrict__ hist,
+                                                     u64* __restrict__ slots) {
+  median_init_body(blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, st, sp, total, hist, slots);
+}
+
+// First kernel of the fused call: the row norms (workgroups [0, row_blocks), one wave per row as in k_rownorms) and, in
+// the PRO_INIT_BLOCKS workgroups behind them, everything the later kernels expect to find zeroed or set up: the
+// median state (median_init_body), the column maxima of the scales and the FuseState tickets.
+constexpr int PRO_INIT_BLOCKS = 16;
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_prologue(const TIN* __restrict__ T, int n, int d, float* __restrict__ r,
+                                                  int row_blocks, SelState* st, SpecState* sp, FuseState* fs, u64 total,
+                                                  u64* __restrict__ hist, u64* __restrict__ slots,
+                                                  u32* __restrict__ cmax, int ncmax) {
+  if ((int)blockIdx.x >= row_blocks) {
+    const int gt = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x, gn = PRO_INIT_BLOCKS * 256;
+    for (int i = gt; i < ncmax; i += gn) cmax[i] = 0u;
+    if (gt < 16) reinterpret_cast<u32*>(fs)[gt] = 0u;
+    median_init_body(gt, gn, st, sp, total, hist, slots);
+    return;
+  }
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const TIN* row = T + (size_t)wave * d;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float x = elem_f32(row + k);
+    s = fmaf(x, x, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) r[wave] = s;
 }
 
 __device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* sp);   // below
@@ -582,10 +632,9 @@ __global__ void k_spec_update(const SelState* st, SpecState* sp) {
   spec_update_dev(st, sp);
 }
 
-// last kernel of the chained radix select (fused call): all three resolves, the median / bandwidth, the predictor update
-__global__ __launch_bounds__(256) void k_resolve_all(const u64* __restrict__ hist_all, SelState* st, SpecState* sp,
-                                                     float ln_n, float* h2_out) {
-  if (sp->hit) return;   // the window produced the median; k_spec_select updated the predictor
+// end of the chained radix select (fused call): all three resolves, the median / bandwidth, the predictor update;
+// one workgroup of 256 threads
+__device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out) {
   const ChainState cs = chain_resolve(hist_all, STEIN_HIST_LEVELS, st);
   if (threadIdx.x == 0) {
     st->prefix[0] = cs.prefix[0]; st->prefix[1] = cs.prefix[1];
@@ -890,7 +939,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   put(STEIN_WS_ROWNORM, (size_t)n * 4);
   put(STEIN_WS_DIST, align_up((size_t)n_local, DT_ROWS) * L->ld_dist * 4);   // tile-major, rows padded to 128
   put(STEIN_WS_HIST, (size_t)STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS * 8);
-  put(STEIN_WS_SELECT, sizeof(SelState) + sizeof(SpecState));
+  put(STEIN_WS_SELECT, sizeof(SelState) + sizeof(SpecState) + sizeof(FuseState));
   put(STEIN_WS_PART_G, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_T, (size_t)split * n_local * d * 4);
   put(STEIN_WS_PART_RS, (size_t)split * n_local * 4);
@@ -1032,19 +1081,19 @@ extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total,
 
 template <int LEVEL>
 static void launch_hist(bool sym, bool chain, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
-                        const SelState* st, u64* h, const u32* skip) {
+                        const SelState* st, u64* h, const u32* skip, const HistFinal& fin) {
   if (sym && chain)
-    hipLaunchKernelGGL((k_hist<LEVEL, true, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
+    hipLaunchKernelGGL((k_hist<LEVEL, true, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip, fin);
   else if (sym)
-    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
+    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip, fin);
   else
-    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
+    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip, fin);
 }
 
 // chain (fused symmetric call only): the pass resolves the earlier levels itself, `hist` is the base of all levels
 static int hist_pass_impl(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
                           const void* select_state, void* hist, int flags, void* stream, const u32* skip,
-                          bool chain = false) {
+                          bool chain = false, const HistFinal& fin = HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
   if (ld_dist < n || (ld_dist & 31) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape (ld_dist must be a multiple of 32)");
@@ -1056,9 +1105,9 @@ static int hist_pass_impl(const float* dist, int64_t ld_dist, int64_t n_local, i
   u64* h = (u64*)hist + (chain ? 0 : (size_t)level * 2 * STEIN_HIST_BINS);
   const SelState* st = (const SelState*)select_state;
   hipStream_t s = (hipStream_t)stream;
-  if (level == 0) launch_hist<0>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
-  else if (level == 1) launch_hist<1>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
-  else launch_hist<2>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  if (level == 0) launch_hist<0>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip, fin);
+  else if (level == 1) launch_hist<1>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip, fin);
+  else launch_hist<2>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip, fin);
   LAUNCH_CHECK("k_hist");
   return STEIN_OK;
 }
@@ -1302,11 +1351,28 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     STEIN_TSTAMP(STEIN_T_NSTAGES);
     return STEIN_OK;
   }
-  if ((rc = stein_rownorms(theta_all, n, d, dtype, r, stream))) return rc;
-  if (planes && (rc = stein_x3_prepare(theta_all, score_all, n, d, dtype, planes, L.total - L.off[STEIN_WS_PLANES], stream)))
+  // The prologue carries the row norms and all set-up; two kernels let their last workgroup do what a one-workgroup
+  // follow-up launch would (FuseState tickets): twelve launches where the separate stages take sixteen.
+  FuseState* fuse = (FuseState*)((char*)sel + sizeof(SelState) + sizeof(SpecState));
+  {
+    u32* cmax = nullptr;
+    int ncmax = 0;
+    if (planes) {   // the column maxima behind the scales (stein_x3.hip)
+      cmax = (u32*)((float*)((char*)planes + L.x3_sc) + 4 * L.x3_dc + 4);
+      ncmax = (int)(2 * L.x3_dc);
+    }
+    const int row_blocks = (int)((n + 3) / 4);
+    const dim3 grid((unsigned)(row_blocks + PRO_INIT_BLOCKS));
+    if (dtype == STEIN_BF16)
+      hipLaunchKernelGGL(k_prologue<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)theta_all, (int)n,
+                         (int)d, r, row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax);
+    else
+      hipLaunchKernelGGL(k_prologue<float>, grid, dim3(256), 0, s, (const float*)theta_all, (int)n, (int)d, r,
+                         row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax);
+    LAUNCH_CHECK("k_prologue");
+  }
+  if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax)))
     return rc;
-  hipLaunchKernelGGL(k_median_init, dim3(16), dim3(256), 0, s, (SelState*)sel, spec, (u64)(n * n), (u64*)hist, spec_buf);
-  LAUNCH_CHECK("k_median_init");
   STEIN_TSTAMP(STEIN_T_DISTANCE);
   if ((rc = distance_block_impl(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream, spec,
                                 spec_buf)))
@@ -1317,15 +1383,13 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   hipLaunchKernelGGL(k_spec_select, dim3(1), dim3(1024), 0, s, (SelState*)sel, spec, spec_buf,
                      (float)log((double)n), h2_out, 1);
   LAUNCH_CHECK("k_spec_select");
-  // chained radix select: three passes that resolve the earlier levels themselves + one kernel for the rest.
-  // Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
+  // chained radix select: three passes that resolve the earlier levels themselves; the last workgroup of the third
+  // resolves the rest.  Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
+  const HistFinal fin{(SelState*)sel, spec, h2_out, &fuse->done_hist, (float)log((double)n)};
   for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv)
     if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit,
-                             true)))
+                             true, lv == STEIN_HIST_LEVELS - 1 ? fin : HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f})))
       return rc;
-  hipLaunchKernelGGL(k_resolve_all, dim3(1), dim3(256), 0, s, (const u64*)hist, (SelState*)sel, spec,
-                     (float)log((double)n), h2_out);
-  LAUNCH_CHECK("k_resolve_all");
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;
   STEIN_TSTAMP(STEIN_T_CONTRACT);
   if ((rc = stein_contract_partial(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, planes,
