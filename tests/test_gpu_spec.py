@@ -105,3 +105,23 @@ def test_timing_flag_reports_every_stage(cuda):
     assert len(calls) == 3
     for c in calls:
         assert set(c) == set(_lib.T_STAGES) and all(v > 0.0 for v in c.values())
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_last_workgroup_tickets_match_separate_launches(cuda, seed):
+    """The fused call lets the last workgroup of k_colmax write the scales and the last workgroup of the level-2 pass do
+    the final resolve (stein_common.h: last_workgroup_out); the staged calls launch k_make_scales / k_resolve instead.
+    Random rescaling makes the window miss, so the chained select really runs.  Both must agree bit for bit."""
+    rng = np.random.default_rng(seed)
+    for n, d in [(129, 17), (333, 130), (777, 64), (1500, 3), (2048, 256), (3000, 128)]:
+        fused = SvgdEngine(n, d, device=cuda, small=False)
+        staged = SvgdEngine(n, d, device=cuda, small=False)
+        for step in range(6):
+            s = float(rng.uniform(0.05, 20.0)) if step % 3 != 2 else 1.0
+            T = torch.randn(n, d, device=cuda) * s
+            G = torch.randn(n, d, device=cuda) * float(rng.uniform(0.01, 100.0))
+            pf = fused.compute_phi(T, G).clone()
+            ps = _staged(staged, T, G).clone()
+            assert float(fused.h2) == float(staged.h2), (n, d, step)
+            assert torch.equal(pf, ps), (n, d, step)
+            assert float(fused.sqnorm) == float(staged.sqnorm), (n, d, step)
