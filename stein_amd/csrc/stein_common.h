@@ -270,7 +270,12 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
         const int lrow4 = tile_m * BM + wy * 64 + i * 32 + 8 * g + h4;  // first of 4 consecutive rows (e & 3)
         const float4 ri4 = *reinterpret_cast<const float4*>(rr + wy * 64 + i * 32 + 8 * g + h4);
         const float ris[4] = {ri4.x, ri4.y, ri4.z, ri4.w};
+        // Four entries at a time, counted without a branch per entry: a workgroup is one wave per SIMD, so the chain
+        // value -> key -> compare -> branch of every single entry ran unhidden (150 cycles per entry, twice the rest of
+        // the epilogue).  The rare cases (a key inside the window, a digit outside the packed counters) are collected
+        // into one flag per group and handled behind one branch.
         float v[4];
+        u32 wq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int lrow = lrow4 + q;
@@ -279,24 +284,46 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
           u32 w = MIRROR ? 2u : 1u;
           if (DIAG) w = lrow < col ? 2u : (lrow == col ? 1u : 0u);
           if (PRED && !(cok && rok)) w = 0u;
+          wq[q] = w;
           if ((!PRED && !DIAG) || w) {
             if (STAGED) stage[(wy * 32 + 8 * g + h4 + q) * EPI_STAGE_LD + wx * 64 + j * 32 + l31] = v[q];
             else D[d_index(lrow, col, ntc)] = v[q];
             if (DIAG && w == 2u) D[d_index(col, lrow, ntc)] = v[q];
-            if (HIST) {
-              const u32 dg = f32_key(v[q]) >> 21;
-              const u32 off = dg - base;
-              if (off < 8u) packed += (u64)w << (8u * off);
-              else atomicAdd(&hl[dg], w);
-            }
-            if (SPEC) {
-              const u32 key = f32_key(v[q]);
-              sx.below += key < sx.lo ? w : 0u;
-              if (key - sx.lo <= sx.width) {   // rare: a fraction of a percent of the entries
+          }
+        }
+        if (HIST) {
+          u32 dg[4];
+          bool far = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            dg[q] = f32_key(v[q]) >> 21;
+            const u32 off = dg[q] - base;
+            const bool near = off < 8u;
+            packed += near ? (u64)wq[q] << (8u * (off & 7u)) : 0ull;
+            far |= !near && wq[q] != 0u;
+          }
+          if (far) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (dg[q] - base >= 8u && wq[q]) atomicAdd(&hl[dg[q]], wq[q]);
+          }
+        }
+        if (SPEC) {
+          u32 key[4];
+          bool any = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            key[q] = f32_key(v[q]);
+            sx.below += key[q] < sx.lo ? wq[q] : 0u;
+            any |= wq[q] != 0u && key[q] - sx.lo <= sx.width;
+          }
+          if (any) {   // rare: a fraction of a percent of the entries
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (wq[q] && key[q] - sx.lo <= sx.width) {
                 const u32 slot = atomicAdd(sx.qcnt, 1u);
-                if (slot < SPEC_QCAP) sx.q[slot] = ((u64)key << 2) | w;
+                if (slot < SPEC_QCAP) sx.q[slot] = ((u64)key[q] << 2) | wq[q];
               }
-            }
           }
         }
         // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (lrow4 % 4 == 0: they stay inside
