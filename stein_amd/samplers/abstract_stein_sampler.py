@@ -115,7 +115,10 @@ class AbstractSteinSampler:
         if isinstance(g, dict):
             g, _ = convert_dictionary_to_array(g)
         if not isinstance(g, torch.Tensor):
-            g = torch.from_numpy(np.ascontiguousarray(np.asarray(g, dtype=np.float64)))
+            g = np.asarray(g)
+            if g.dtype not in (np.float32, np.float64):     # the reference hands over float64; float32 goes up as it is
+                g = g.astype(np.float64)
+            g = torch.from_numpy(np.ascontiguousarray(g))
         if tuple(g.shape) != (self.n_local, self.n_params):
             raise ValueError("score must be [%d, %d], got %s" % (self.n_local, self.n_params, tuple(g.shape)))
         return g.to(device=self.device, dtype=self.kernel_dtype).contiguous()
