@@ -65,8 +65,9 @@ enum {
   STEIN_WS_ROWNORM = 0,  /* float  [n]                      r_i = |theta_i|^2                     */
   STEIN_WS_DIST = 1,     /* float  [n_local][ld_dist]       squared distances, row block          */
   STEIN_WS_HIST = 2,     /* int64  [3 levels][2][2048]      radix-select histograms               */
-  STEIN_WS_SELECT = 3,   /* 128 B  select state (ranks, prefixes, median, h2) + the speculative-window state,
-                            which must persist from one stein_svgd_phi call to the next              */
+  STEIN_WS_SELECT = 3,   /* 192 B  select state (ranks, prefixes, median, h2) + the speculative-window state,
+                            which must persist from one stein_svgd_phi call to the next, + 64 B of
+                            launch tickets private to stein_svgd_phi                                  */
   STEIN_WS_PART_G = 4,   /* float  [split][n_local][d]      partial K.G                           */
   STEIN_WS_PART_T = 5,   /* float  [split][n_local][d]      partial K.theta                       */
   STEIN_WS_PART_RS = 6,  /* float  [split][n_local]         partial rowsum(K)                     */
