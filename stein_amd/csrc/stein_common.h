@@ -288,7 +288,19 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
           if ((!PRED && !DIAG) || w) {
             if (STAGED) stage[(wy * 32 + 8 * g + h4 + q) * EPI_STAGE_LD + wx * 64 + j * 32 + l31] = v[q];
             else D[d_index(lrow, col, ntc)] = v[q];
-            if (DIAG && w == 2u) D[d_index(col, lrow, ntc)] = v[q];
+          }
+        }
+        if (DIAG) {
+          // mirror images: a group whose four rows all lie above the diagonal goes out as one 16-byte store (4
+          // consecutive columns of row `col`, as in the off-diagonal tiles); only the groups that straddle the
+          // diagonal fall back to single entries.  (One scattered dword store per entry made the diagonal tiles 2.5x
+          // as slow as the others, and they are the critical path of every launch that fits the chip in one round.)
+          if (wq[0] == 2u && wq[3] == 2u) {
+            *reinterpret_cast<float4*>(D + d_index(col, lrow4, ntc)) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (wq[q] == 2u) D[d_index(col, lrow4 + q, ntc)] = v[q];
           }
         }
         if (HIST) {
