@@ -128,7 +128,7 @@ class NumpyStages:
         hist.zero_()
         self._st = SelectState(total)
         sp = getattr(self, "_sp", None) or dict(magic=0, center=0, halfwidth=0, last_key=0)
-        ok = sp["magic"] in (1, 2) and sp["halfwidth"] <= self.HW_MAX and sp["halfwidth"] <= sp["center"] <= 0xFFFFFFFE - sp["halfwidth"]
+        ok = sp["magic"] in (1, 2) and sp["halfwidth"] <= self.HW_MAX and 0x80000000 + sp["halfwidth"] <= sp["center"] < 0xFF000000 - sp["halfwidth"]
         sp.update(lo=sp["center"] - sp["halfwidth"] if ok else 0xFFFFFFFF, width=2 * sp["halfwidth"] if ok else 0,
                   count=0, hit=False, below=0, total=total, entries=np.zeros(0, dtype=np.int64))
         sp["skip_l0"] = sp["width"] == 0

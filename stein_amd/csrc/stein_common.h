@@ -235,7 +235,7 @@ __device__ __forceinline__ void distance_store_rows(const float* __restrict__ st
 }
 
 struct SpecCtx {   // per-thread view of the speculative window (SPEC epilogues only)
-  u32 lo, width;   // window [lo, lo + width] in key space
+  u32 lo, width;   // window: raw bit patterns [lo, lo + width] of positive floats (key = bits | 0x80000000)
   u32* qcnt;       // LDS: entries pushed by this workgroup
   u64* q;          // LDS queue, SPEC_QCAP entries of (key << 2 | weight)
   u32 below;       // this thread's weight of entries below the window
@@ -259,6 +259,7 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const int l31 = lane & 31, h4 = (lane >> 5) * 4;
+  u32 below_cnt = 0u;   // SPEC, uniform weight: entries below the window, weighted once at the end
   {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -321,20 +322,25 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
           }
         }
         if (SPEC) {
-          u32 key[4];
-          bool any = false;
+          // The window lies among the keys of positive floats (median_init_body grants no other), where the key is
+          // the bit pattern with the sign bit set: "below the window" is a signed compare of the raw bits (negative
+          // values included) and "inside" an unsigned range test on them -- no key is formed unless an entry is caught.
+          u32 off[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            key[q] = f32_key(v[q]);
-            sx.below += key[q] < sx.lo ? wq[q] : 0u;
-            any |= wq[q] != 0u && key[q] - sx.lo <= sx.width;
+            const u32 raw = __float_as_uint(v[q]);
+            const bool lower = (int)raw < (int)sx.lo;
+            if (!PRED && !DIAG) below_cnt += lower ? 1u : 0u;
+            else sx.below += lower ? wq[q] : 0u;
+            off[q] = raw - sx.lo;
+            if ((PRED || DIAG) && wq[q] == 0u) off[q] = 0xffffffffu;
           }
-          if (any) {   // rare: a fraction of a percent of the entries
+          if (min(min(off[0], off[1]), min(off[2], off[3])) <= sx.width) {   // rare: a fraction of a percent of the entries
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (wq[q] && key[q] - sx.lo <= sx.width) {
+              if (off[q] <= sx.width) {
                 const u32 slot = atomicAdd(sx.qcnt, 1u);
-                if (slot < SPEC_QCAP) sx.q[slot] = ((u64)key[q] << 2) | wq[q];
+                if (slot < SPEC_QCAP) sx.q[slot] = ((u64)(__float_as_uint(v[q]) | 0x80000000u) << 2) | wq[q];
               }
           }
         }
@@ -345,6 +351,27 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
       }
     }
   }
+  if (SPEC && !PRED && !DIAG) sx.below += below_cnt * (MIRROR ? 2u : 1u);
+}
+
+// What the epilogue needs from global memory, fetched BEFORE the main loop so that the latency (two dependent trips:
+// about 2 us per workgroup, 0.04 ms of the C3 launch) hides under it: this thread's entry of the tile's row / column
+// norms and this step's window.
+struct EpiPrefetch {
+  float norm;          // thread t < 128: r of tile row t, else r of tile column t - 128 (0 outside the matrix)
+  u32 lo_key, width;   // SpecState window (width 0: none)
+};
+__device__ __forceinline__ EpiPrefetch distance_epilogue_prefetch(const float* __restrict__ r, int n, int row0,
+                                                                  int n_local, int tile_m, int tile_n,
+                                                                  const SpecState* __restrict__ spec) {
+  EpiPrefetch pf;
+  const int t = threadIdx.x;
+  const int idx = t < BM ? tile_m * BM + t : tile_n * BN + (t - BM);
+  const bool ok = t < BM ? idx < n_local : idx < n;
+  pf.norm = ok ? r[(t < BM ? row0 : 0) + idx] : 0.f;
+  pf.lo_key = spec ? spec->lo_key : 0xffffffffu;
+  pf.width = spec ? spec->width : 0u;
+  return pf;
 }
 
 // `lds` is the kernel's shared array, EPI_LDS_BYTES at least, which the caller no longer needs (all waves must be past
@@ -354,7 +381,8 @@ template <bool SYM>
 __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* lds, const float* __restrict__ r,
                                                   float* __restrict__ D, int n, int row0, int n_local, long ldD,
                                                   int tile_m, int tile_n, u64* __restrict__ hist0,
-                                                  float two_s = 2.f, SpecState* __restrict__ spec = nullptr,
+                                                  const EpiPrefetch& pf, float two_s = 2.f,
+                                                  SpecState* __restrict__ spec = nullptr,
                                                   u64* __restrict__ spec_buf = nullptr) {
   // two_s: D = r_i + r_j - two_s * acc.  2 for S = T T^T accumulated at full scale; the split kernels accumulate the
   // product of operands pre-scaled by a power of two and pass 2 / scale^2 (exact either way)
@@ -372,24 +400,20 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
   static_assert(8 * SPEC_QCAP <= 4 * STEIN_HIST_BINS, "the window queue lives in the histogram's LDS");
   float* rr = reinterpret_cast<float*>(hl + STEIN_HIST_BINS + 16);   // [128] row norms, [128] column norms
   float* rc = rr + BM;
-  {
-    const int idx = t < BM ? tile_m * BM + t : brow0 + (t - BM);
-    const bool ok = t < BM ? idx < n_local : idx < n;
-    rr[t] = ok ? r[(t < BM ? row0 : 0) + idx] : 0.f;
-  }
+  rr[t] = pf.norm;
   // A step with a window (spec->width != 0) skips the level-0 histogram: it is only needed when the window misses,
   // and then a k_hist<0> pass over D supplies it (SpecState::skip_l0).
-  const bool window = spec && spec->width != 0u;
+  const bool window = spec && pf.width != 0u;
   const bool hist = hist0 && !window;
   if (window) {
     if (t == 0) { sx.qcnt[0] = 0u; sx.qcnt[2] = 0u; }
-    sx.lo = spec->lo_key;
-    sx.width = spec->width;
+    sx.lo = pf.lo_key & 0x7fffffffu;   // raw bits of the window's first value (a positive float)
+    sx.width = pf.width;
   }
   if (hist) {
     for (int b = t; b < STEIN_HIST_BINS; b += NTHREADS) hl[b] = 0u;
     __syncthreads();
-    const float v0 = (r[min(row0 + tile_m * BM + wy * 64, n - 1)] + r[min(brow0 + wx * 64, n - 1)]) - two_s * acc[0][0][0];
+    const float v0 = (rr[wy * 64] + rc[wx * 64]) - two_s * acc[0][0][0];   // any value will do: it only centres the packed counters
     base = (u32)__builtin_amdgcn_readfirstlane((int)(f32_key(v0) >> 21));
     base = base < 3u ? 0u : base - 3u;  // window start
   } else {

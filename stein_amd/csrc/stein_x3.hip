@@ -406,6 +406,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const long arow0 = row0 + (long)tile_m * BM, brow0 = (long)tile_n * BN;
+  const EpiPrefetch pf = distance_epilogue_prefetch(r, n, row0, n_local, tile_m, tile_n, spec);
+  const float two_s_v = *two_s;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
     __syncthreads();
     STAMP(1);
   }
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, *two_s,
-                         spec, spec_buf);
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, pf,
+                         two_s_v, spec, spec_buf);
 #ifdef STEIN_STAMPS
   STAMP(3);     // epilogue
   if (t == 0) {

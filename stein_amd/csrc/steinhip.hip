@@ -143,6 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
   const int lr = t >> 3, lc = (t & 7) * 4;
   const int arow0 = row0 + tile_m * BM;  // global particle index of the tile's first row
   const int brow0 = tile_n * BN;
+  const EpiPrefetch pf = distance_epilogue_prefetch(r, n, row0, n_local, tile_m, tile_n, spec);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
   }
 
   // the staging tiles are dead (every wave is past the loop's last barrier): 8 KB of them hold the level-0 histogram
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, 2.f,
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, pf, 2.f,
                          spec, spec_buf);
 }
 
@@ -395,8 +396,10 @@ __device__ __forceinline__ void median_init_body(int gt, int gn, SelState* st, S
     st->even = even;
     st->median = st->h2 = st->lo = st->hi = 0.f;
   }
+  // a window is granted only among the keys of positive finite floats, [0x80000000, 0xff000000): the distance epilogue
+  // tests raw bit patterns (a median <= 0 means coincident particles: h2 = 0, nothing to speed up)
   if ((sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) && sp->halfwidth <= SPEC_HW_MAX &&
-      sp->center >= sp->halfwidth && sp->center <= 0xfffffffeu - sp->halfwidth) {
+      sp->center >= 0x80000000u + sp->halfwidth && sp->center < 0xff000000u - sp->halfwidth) {
     sp->lo_key = sp->center - sp->halfwidth;
     sp->width = 2u * sp->halfwidth;
   } else {
