@@ -315,7 +315,7 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
             packed += near ? (u64)wq[q] << (8u * (off & 7u)) : 0ull;
             far |= !near && wq[q] != 0u;
           }
-          if (far) {
+          if (__builtin_expect(far, 0)) {   // cold: laid out behind the hot path, which then falls through its branch
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               if (dg[q] - base >= 8u && wq[q]) atomicAdd(&hl[dg[q]], wq[q]);
@@ -335,7 +335,7 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
             off[q] = raw - sx.lo;
             if ((PRED || DIAG) && wq[q] == 0u) off[q] = 0xffffffffu;
           }
-          if (min(min(off[0], off[1]), min(off[2], off[3])) <= sx.width) {   // rare: a fraction of a percent of the entries
+          if (__builtin_expect(min(min(off[0], off[1]), min(off[2], off[3])) <= sx.width, 0)) {   // rare: a fraction of a percent of the entries
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               if (off[q] <= sx.width) {
