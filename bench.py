@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
     ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief C1 / C2 / C4 timings (one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -306,6 +307,17 @@ def main():
                 "contract_tflops": f2 / (k2 * 1e-3) / 1e12 if k2 else None,
                 "stage_ms": {k: round(v, 4) for k, v in r2["stages"].items()}, "finite": r2["finite"],
             }
+    # one GPU: the remaining BASELINE configs (parity-test cases, timed briefly for the record; not the headline value)
+    if world == 1 and args.workload == "c3" and not args.no_other_configs:
+        others = {}
+        for key in ("c1", "c2", "c4"):
+            torch.cuda.empty_cache()
+            ro = run_workload(torch, dist, args, dict(WORKLOADS[key]), device, rank, world, group, 20, 3, clock_stages=False)
+            others[key] = {"workload": WORKLOADS[key]["name"], "n": ro["n"], "d": ro["d"], "steps": 20,
+                           "ms_per_step": ro["elapsed"] / 20 * 1e3, "value": ro["n"] * 20 / ro["elapsed"],
+                           "unit": "particle-updates/s", "finite": ro["finite"]}
+            del ro
+        out["other_configs"] = others
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
