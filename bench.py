@@ -11,7 +11,8 @@ speculative median window -> exact median -> fused exp + split-precision MFMA co
 BASELINE.json's roofline config "n=16384, d=256, fp32" (C3, the configuration the north star's contraction
 target is quoted on); with N ranks the same n is sharded by rows (strong scaling): all-gathers of the theta and G
 rows, the median collectives (stein_amd/engine.py) and one scalar all-reduce per step over RCCL.  The secondary
-entry times C5 (n=131072) the same way.
+entry times C5 (n=131072) the same way; a one-GPU run also times the other BASELINE configs (C1, C2 bf16, C4) for 20
+steps each and reports them under `other_configs` (they are parity-test cases, not the headline value).
 
 value = n * K / (max-over-ranks wall time of the K timed steps), bracketed by barrier + synchronize.
 roofline: the K.[G|theta] contraction kernel (k_phi_x3fs, or k_phi_partial with STEIN_X3=0), algorithmic flops
