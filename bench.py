@@ -317,6 +317,9 @@ def main():
             others[key] = {"workload": WORKLOADS[key]["name"], "n": ro["n"], "d": ro["d"], "steps": 20,
                            "ms_per_step": ro["elapsed"] / 20 * 1e3, "value": ro["n"] * 20 / ro["elapsed"],
                            "unit": "particle-updates/s", "finite": ro["finite"]}
+            if not args.no_cpu_baseline:     # the NumPy oracle on the same inputs (C4: a bounded row block)
+                others[key]["cpu_baseline"] = cpu_baseline(WORKLOADS[key], ro["T64"], ro["G64"],
+                                                           2048 if key == "c4" else ro["n"])
             del ro
         out["other_configs"] = others
     if rank == 0:
