@@ -204,8 +204,19 @@ __global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, cons
   const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
   const int col = blockIdx.x * 64 + cx;
   u32 m = 0u;
-  if (col < d)
-    for (long r = (long)blockIdx.y * 4 + ry; r < n; r += (long)gridDim.y * 4) m = max(m, abs_bits(X[(size_t)r * d + col]));
+  if (col < d) {
+    // four independent loads in flight per lane (one dependent load at a time read the matrices at 2 TB/s)
+    const long step = (long)gridDim.y * 4;
+    long r = (long)blockIdx.y * 4 + ry;
+    u32 m1 = 0u, m2 = 0u, m3 = 0u;
+    for (; r + 3 * step < n; r += 4 * step) {
+      const u32 a0 = abs_bits(X[(size_t)r * d + col]), a1 = abs_bits(X[(size_t)(r + step) * d + col]);
+      const u32 a2 = abs_bits(X[(size_t)(r + 2 * step) * d + col]), a3 = abs_bits(X[(size_t)(r + 3 * step) * d + col]);
+      m = max(m, a0); m1 = max(m1, a1); m2 = max(m2, a2); m3 = max(m3, a3);
+    }
+    for (; r < n; r += step) m = max(m, abs_bits(X[(size_t)r * d + col]));
+    m = max(max(m, m1), max(m2, m3));
+  }
   red[ry][cx] = m;
   __syncthreads();
   if (ry == 0 && col < d) atomicMax(&cmax[col], max(max(red[0][cx], red[1][cx]), max(red[2][cx], red[3][cx])));
