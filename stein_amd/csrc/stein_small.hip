@@ -23,9 +23,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
                                                            int d, float ln_n, float* __restrict__ phi,
                                                            float* __restrict__ h2_out, double* __restrict__ sqpart,
                                                            float* __restrict__ K_out, float* __restrict__ dK_out) {
-  extern __shared__ float sm[];
-  const int ldn = n + 1;
-  float* Dm = sm;                                   // [n][n + 1]  distances, then K
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ldn = (n + 3) & ~3;   // rows start 16-byte aligned (the phi stage reads K four columns at a time)
+  float* Dm = sm;                                   // [n][ldn]  distances, then K
   float* tc = Dm + (size_t)n * ldn;                 // [n][SM_CK + 1] theta chunk
   float* rn = tc + (size_t)n * (SM_CK + 1);         // [n] row norms, later rowsum(K)
   u32* hist = reinterpret_cast<u32*>(rn + n);       // [2][2048]
@@ -196,32 +196,65 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     gs[j * SM_COLS + cl] = ok ? G[(size_t)j * d + cw0 + cl] : 0.f;
   }
   __syncthreads();
-  // one wave per row i: lane -> column (lane & 31) and half of the j range (lane >> 5); K_ij is a broadcast read, the
-  // staged score / theta entries of 32 consecutive lanes are consecutive words
+  // A wave owns the rows wave + 16 r (r < RB = ceil(n / 16)); lane -> column (lane & 31) and half of the j range
+  // (lane >> 5).  All RB rows advance together: per four j one 16-byte broadcast read of K per row and the staged score /
+  // theta entries once, for 8 RB FMAs -- one row at a time read three words per two FMAs and the stage was bound by LDS
+  // bandwidth (61 k of the kernel's 144 k cycles at n = 128).
   double sq = 0.0;
   const float fn = (float)n;
   const int cl = lane & 31, jh = lane >> 5;
-  const int jmid = (n + 1) / 2, j0 = jh ? jmid : 0, j1 = jh ? n : jmid;
-  for (int i = wave; i < n; i += SM_THREADS / 64) {
-    const float* krow = Dm + i * ldn;
-    float kg = 0.f, kt = 0.f;
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-      const float k = krow[j];
-      kg = fmaf(k, gs[j * SM_COLS + cl], kg);
-      kt = fmaf(k, ts[j * (SM_COLS + 1) + cl], kt);
+  const int jmid = min(n, (((n + 1) / 2) + 3) & ~3), j0 = jh ? jmid : 0, j1 = jh ? n : jmid;
+  auto phi_rows = [&](auto rb_tag) {
+    constexpr int RB = decltype(rb_tag)::value;
+    float kg[RB], kt[RB];
+    const float* krow[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      kg[r] = kt[r] = 0.f;
+      krow[r] = Dm + min(wave + (SM_THREADS / 64) * r, n - 1) * ldn;   // rows past n repeat row n - 1 (never stored)
     }
-    kg += __shfl_xor(kg, 32);
-    kt += __shfl_xor(kt, 32);
-    if (jh == 0 && cl < ncols) {
-      const int c = cw0 + cl;
-      const float dk = (rn[i] * ts[i * (SM_COLS + 1) + cl] - kt) / h2;   // squared_exponential_kernel.py:28-35
-      const float ph = (kg + dk) / fn;                                    // abstract_stein_sampler.py:105
-      phi[(size_t)i * d + c] = ph;
-      if (dK_out) dK_out[(size_t)i * d + c] = dk;
-      sq += (double)ph * (double)ph;
+    int j = j0;
+    for (; j + 3 < j1; j += 4) {
+      float4 k4[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) k4[r] = *reinterpret_cast<const float4*>(krow[r] + j);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float g = gs[(j + jj) * SM_COLS + cl], tt = ts[(j + jj) * (SM_COLS + 1) + cl];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const float k = jj == 0 ? k4[r].x : (jj == 1 ? k4[r].y : (jj == 2 ? k4[r].z : k4[r].w));
+          kg[r] = fmaf(k, g, kg[r]);
+          kt[r] = fmaf(k, tt, kt[r]);
+        }
+      }
     }
-  }
+    for (; j < j1; ++j) {
+      const float g = gs[j * SM_COLS + cl], tt = ts[j * (SM_COLS + 1) + cl];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const float k = krow[r][j];
+        kg[r] = fmaf(k, g, kg[r]);
+        kt[r] = fmaf(k, tt, kt[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const float sg = kg[r] + __shfl_xor(kg[r], 32), st = kt[r] + __shfl_xor(kt[r], 32);
+      const int i = wave + (SM_THREADS / 64) * r;
+      if (jh == 0 && cl < ncols && i < n) {
+        const int c = cw0 + cl;
+        const float dk = (rn[i] * ts[i * (SM_COLS + 1) + cl] - st) / h2;   // squared_exponential_kernel.py:28-35
+        const float ph = (sg + dk) / fn;                                    // abstract_stein_sampler.py:105
+        phi[(size_t)i * d + c] = ph;
+        if (dK_out) dK_out[(size_t)i * d + c] = dk;
+        sq += (double)ph * (double)ph;
+      }
+    }
+  };
+  if (n <= 2 * (SM_THREADS / 64)) phi_rows(std::integral_constant<int, 2>());         // workgroup-uniform
+  else if (n <= 4 * (SM_THREADS / 64)) phi_rows(std::integral_constant<int, 4>());
+  else phi_rows(std::integral_constant<int, 8>());
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0) s_red[wave] = sq;
@@ -242,7 +275,7 @@ bool stein_small_ok(int64_t n, int64_t d, int dtype) {
 int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
                     double* sqpart, float* K_out, float* dK_out, int* nparts, hipStream_t stream) {
   const int blocks = (int)((d + SM_COLS - 1) / SM_COLS);
-  const size_t lds = ((size_t)n * (n + 1) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + 2 * STEIN_HIST_BINS * sizeof(u32);
+  const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + 2 * STEIN_HIST_BINS * sizeof(u32);
   static bool attr_set = false;
   if (!attr_set) {   // more than the default 64 KB of dynamic LDS
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svgd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
