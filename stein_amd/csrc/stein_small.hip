@@ -115,13 +115,17 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     const bool two = s_div != 0u;
     for (int b = t; b < (two ? 2 : 1) * STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;
     __syncthreads();
-    for (u32 e = t; e < total; e += SM_THREADS) {
-      const u32 key = f32_key(Dm[(e / n) * ldn + (e % n)]);
-      const u32 digit = (key >> shift) & ((1u << bits) - 1u);
-      const u32 hi = level == 0 ? 0u : key >> (shift + bits);
-      if (level == 0 || hi == pa) atomicAdd(&hist[digit], 1u);
-      if (two && hi == pb) atomicAdd(&hist[STEIN_HIST_BINS + digit], 1u);
-    }
+    for (int r = 0; r < R; ++r)          // the distance stage's entry map: (bi + 32 r, bj + 32 q), no divisions
+      for (int q = 0; q < R; ++q) {
+        const int i = bi + 32 * r, j = bj + 32 * q;
+        if (i < n && j < n) {
+          const u32 key = f32_key(Dm[i * ldn + j]);
+          const u32 digit = (key >> shift) & ((1u << bits) - 1u);
+          const u32 hi = level == 0 ? 0u : key >> (shift + bits);
+          if (level == 0 || hi == pa) atomicAdd(&hist[digit], 1u);
+          if (two && hi == pb) atomicAdd(&hist[STEIN_HIST_BINS + digit], 1u);
+        }
+      }
     __syncthreads();
     // locate each target's digit with a workgroup-wide prefix sum over the 2048 bins (two bins per thread); a
     // single thread walking the bins took 65 us per level.  While the targets share a prefix (almost always until the
@@ -166,20 +170,25 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   }
   __syncthreads();
   const float h2 = s_h2;
-  // ---- K in place, rowsum(K) ----
-  for (u32 e = t; e < total; e += SM_THREADS) {
-    const int i = e / n, j = e % n;
-    const float k = expf(-Dm[i * ldn + j] / h2 / 2.f);
-    Dm[i * ldn + j] = k;
-    if (K_out && blockIdx.x == 0) K_out[(size_t)i * n + j] = k;
-  }
-  __syncthreads();
-  for (int i = wave; i < n; i += SM_THREADS / 64) {
+  // ---- K in place (exp(-D / h2 / 2) = exp2(kc D), as the tiled kernels form it), rowsum(K): the 32 lanes that share
+  //      bi hold 32 columns of a row, so a row's sum is R shuffle reductions, added in a fixed order ----
+  const float kc = -1.44269504088896341f / (2.f * h2);
+  for (int r = 0; r < R; ++r) {
+    const int i = bi + 32 * r;
     float s = 0.f;
-    for (int j = lane; j < n; j += 64) s += Dm[i * ldn + j];
+    for (int q = 0; q < R; ++q) {
+      const int j = bj + 32 * q;
+      float k = 0.f;
+      if (i < n && j < n) {
+        k = __builtin_amdgcn_exp2f(kc * Dm[i * ldn + j]);
+        Dm[i * ldn + j] = k;
+        if (K_out && blockIdx.x == 0) K_out[(size_t)i * n + j] = k;
+      }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) rn[i] = s;
+      for (int o = 16; o > 0; o >>= 1) k += __shfl_xor(k, o);
+      s += k;
+    }
+    if (bj == 0 && i < n) rn[i] = s;
   }
   __syncthreads();
   // ---- phi for this workgroup's SM_COLS columns.  Their theta / score columns are staged in LDS first (the chunk
