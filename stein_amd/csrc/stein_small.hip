@@ -34,29 +34,24 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   __shared__ double s_red[SM_THREADS / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-  // ---- row norms (abstract_kernel.py:34): one wave per row ----
-  for (int i = wave; i < n; i += SM_THREADS / 64) {
-    float s = 0.f;
-    for (int c = lane; c < d; c += 64) { const float v = T[(size_t)i * d + c]; s = fmaf(v, v, s); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) rn[i] = s;
-  }
   // ---- S = T T^T, theta staged SM_CK columns at a time.  Thread (bi, bj) = (t / 32, t % 32) owns the entries
   //      (bi + 32 r, bj + 32 s), r, s < R = ceil(n / 32): 2 R LDS reads feed R^2 FMAs per column, the row reads are
   //      broadcasts and the column reads of 32 consecutive lanes hit 32 different banks (row stride 33).  (One thread
   //      per (i <= j) pair read two words per FMA: 23 MB of LDS reads, 90 us, for n = 20, d = 303.) ----
+  for (int b = t; b < STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;   // level-0 histogram, filled by the distance stage
   const int bi = t >> 5, bj = t & 31;
   const int R = (n + 31) >> 5;
   const bool mine = bi < n && bj < n;
   // RR = R as a compile-time constant: the inner loop is 2 RR LDS reads (fixed row offsets) and RR^2 FMAs per column
   auto distances = [&](auto rr_tag) {
     constexpr int RR = decltype(rr_tag)::value;
-    float acc[RR][RR];
-#pragma unroll
-    for (int r = 0; r < RR; ++r)
+    float acc[RR][RR], na[RR], nb[RR];   // na / nb: squared norms of this thread's rows / columns (abstract_kernel.py:34),
+#pragma unroll                          // summed in column order by every thread that needs them -- identical everywhere
+    for (int r = 0; r < RR; ++r) {
+      na[r] = nb[r] = 0.f;
 #pragma unroll
       for (int q = 0; q < RR; ++q) acc[r][q] = 0.f;
+    }
     const float* pa[RR];
     const float* pb[RR];
 #pragma unroll
@@ -72,11 +67,16 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
       }
       __syncthreads();
       if (mine) {
+        const int cend = min(SM_CK, d - c0);
 #pragma unroll 8
-        for (int c = 0; c < SM_CK; ++c) {
+        for (int c = 0; c < cend; ++c) {
           float a[RR], b[RR];
 #pragma unroll
-          for (int r = 0; r < RR; ++r) { a[r] = pa[r][c]; b[r] = pb[r][c]; }
+          for (int r = 0; r < RR; ++r) {
+            a[r] = pa[r][c]; b[r] = pb[r][c];
+            na[r] = fmaf(a[r], a[r], na[r]);
+            nb[r] = fmaf(b[r], b[r], nb[r]);
+          }
 #pragma unroll
           for (int r = 0; r < RR; ++r)
 #pragma unroll
@@ -90,7 +90,11 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
 #pragma unroll
         for (int q = 0; q < RR; ++q) {
           const int i = bi + 32 * r, j = bj + 32 * q;
-          if (i < n && j < n) Dm[i * ldn + j] = (rn[i] + rn[j]) - 2.f * acc[r][q];      // abstract_kernel.py:35
+          if (i < n && j < n) {
+            const float v = (na[r] + nb[q]) - 2.f * acc[r][q];      // abstract_kernel.py:35
+            Dm[i * ldn + j] = v;
+            atomicAdd(&hist[f32_key(v) >> 21], 1u);                  // level 0 of the radix select, while the value is at hand
+          }
         }
     }
   };
@@ -113,9 +117,11 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0), bits = level == 2 ? 10 : 11;
     const u32 pa = s_prefix[0], pb = s_prefix[1];
     const bool two = s_div != 0u;
-    for (int b = t; b < (two ? 2 : 1) * STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;
-    __syncthreads();
-    for (int r = 0; r < R; ++r)          // the distance stage's entry map: (bi + 32 r, bj + 32 q), no divisions
+    if (level > 0) {
+      for (int b = t; b < (two ? 2 : 1) * STEIN_HIST_BINS; b += SM_THREADS) hist[b] = 0u;
+      __syncthreads();
+    }
+    for (int r = 0; r < (level > 0 ? R : 0); ++r)   // the distance stage's entry map: (bi + 32 r, bj + 32 q), no divisions
       for (int q = 0; q < R; ++q) {
         const int i = bi + 32 * r, j = bj + 32 * q;
         if (i < n && j < n) {
