@@ -541,4 +541,5 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
 bool stein_small_ok(int64_t n, int64_t d, int dtype);
 int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
                     double* sqpart /* one partial |phi|^2 per workgroup, *nparts of them (<= ceil(d / 32)) */,
-                    float* K_out, float* dK_out, int* nparts, hipStream_t stream);
+                    float* K_out, float* dK_out, int* nparts /* 0: a single workgroup wrote *sqnorm_out itself */,
+                    double* sqnorm_out, hipStream_t stream);

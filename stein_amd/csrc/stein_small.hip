@@ -22,7 +22,8 @@ static_assert(SM_COLS == SM_CK, "the theta chunk buffer doubles as the phi stage
 __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restrict__ T, const float* __restrict__ G, int n,
                                                            int d, float ln_n, float* __restrict__ phi,
                                                            float* __restrict__ h2_out, double* __restrict__ sqpart,
-                                                           float* __restrict__ K_out, float* __restrict__ dK_out) {
+                                                           float* __restrict__ K_out, float* __restrict__ dK_out,
+                                                           double* __restrict__ sq_total) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ldn = (n + 3) & ~3;   // rows start 16-byte aligned (the phi stage reads K four columns at a time)
   float* Dm = sm;                                   // [n][ldn]  distances, then K
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     double s = 0.0;
     for (int w = 0; w < SM_THREADS / 64; ++w) s += s_red[w];
     sqpart[blockIdx.x] = s;
+    if (gridDim.x == 1 && sq_total) *sq_total = s;   // d <= 32: this workgroup's partial is the whole |phi|^2
   }
 }
 
@@ -288,7 +290,7 @@ bool stein_small_ok(int64_t n, int64_t d, int dtype) {
 }
 
 int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
-                    double* sqpart, float* K_out, float* dK_out, int* nparts, hipStream_t stream) {
+                    double* sqpart, float* K_out, float* dK_out, int* nparts, double* sqnorm_out, hipStream_t stream) {
   const int blocks = (int)((d + SM_COLS - 1) / SM_COLS);
   const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + 2 * STEIN_HIST_BINS * sizeof(u32);
   static bool attr_set = false;
@@ -298,8 +300,8 @@ int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d
     attr_set = true;
   }
   hipLaunchKernelGGL(k_svgd_small, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, theta, score, (int)n, (int)d,
-                     (float)log((double)n), phi, h2_out, sqpart, K_out, dK_out);
+                     (float)log((double)n), phi, h2_out, sqpart, K_out, dK_out, sqnorm_out);
   LAUNCH_CHECK("k_svgd_small");
-  *nparts = blocks;
+  *nparts = blocks == 1 ? 0 : blocks;   // one workgroup: it has written *sqnorm_out itself
   return STEIN_OK;
 }

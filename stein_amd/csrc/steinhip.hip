@@ -1346,11 +1346,13 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     int nparts = 0;
     double* sqp = (double*)(ws + L.off[STEIN_WS_SQPART]);
     if ((rc = stein_small_phi((const float*)theta_all, (const float*)score_all, n, d, phi_local, h2_out, sqp, K_out,
-                              dK_out, &nparts, s)))
+                              dK_out, &nparts, sqnorm_out, s)))
       return rc;
     STEIN_TSTAMP(STEIN_T_FINISH);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const double*)sqp, nparts, sqnorm_out);
-    LAUNCH_CHECK("k_sum_partials");
+    if (nparts) {   // d > 32: several workgroups, their partials are summed here
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const double*)sqp, nparts, sqnorm_out);
+      LAUNCH_CHECK("k_sum_partials");
+    }
     STEIN_TSTAMP(STEIN_T_NSTAGES);
     return STEIN_OK;
   }
