@@ -60,12 +60,26 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
       pa[r] = tc + min(bi + 32 * r, n - 1) * (SM_CK + 1);
       pb[r] = tc + min(bj + 32 * r, n - 1) * (SM_CK + 1);
     }
+    // the next chunk's theta entries travel from global memory into registers while this chunk is multiplied
+    // (n * SM_CK <= 4 * SM_THREADS entries: at most four per thread)
+    static_assert(SM_MAXN * SM_CK <= 4 * SM_THREADS, "four staged entries per thread");
+    float pre[4];
+    auto fetch = [&](int c0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = t + k * SM_THREADS, i = e / SM_CK, c = e % SM_CK;
+        pre[k] = (e < n * SM_CK && c0 + c < d) ? T[(size_t)i * d + c0 + c] : 0.f;   // zero-filled past d
+      }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < d; c0 += SM_CK) {
       __syncthreads();
-      for (int e = t; e < n * SM_CK; e += SM_THREADS) {
-        const int i = e / SM_CK, c = e % SM_CK;
-        tc[i * (SM_CK + 1) + c] = c0 + c < d ? T[(size_t)i * d + c0 + c] : 0.f;   // zero-filled past d
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = t + k * SM_THREADS;
+        if (e < n * SM_CK) tc[(e / SM_CK) * (SM_CK + 1) + e % SM_CK] = pre[k];
       }
+      if (c0 + SM_CK < d) fetch(c0 + SM_CK);
       __syncthreads();
       if (mine) {
         const int cend = min(SM_CK, d - c0);
@@ -104,6 +118,17 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     case 2: distances(std::integral_constant<int, 2>()); break;
     case 3: distances(std::integral_constant<int, 3>()); break;
     default: distances(std::integral_constant<int, 4>()); break;
+  }
+  // this workgroup's theta / score columns for the phi stage: requested now, so the loads fly during the median
+  const int cw0 = blockIdx.x * SM_COLS;
+  const int ncols = min(SM_COLS, d - cw0);
+  float preT[4], preG[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + k * SM_THREADS, j = e / SM_COLS, cl = e % SM_COLS;
+    const bool ok = e < n * SM_COLS && cl < ncols;
+    preT[k] = ok ? T[(size_t)j * d + cw0 + cl] : 0.f;
+    preG[k] = ok ? G[(size_t)j * d + cw0 + cl] : 0.f;
   }
   // ---- exact median of the n^2 entries: 3-level radix select (11 / 11 / 10 bits), two targets for an even count ----
   const u32 total = (u32)n * (u32)n;
@@ -201,15 +226,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   // ---- phi for this workgroup's SM_COLS columns.  Their theta / score columns are staged in LDS first (the chunk
   //      buffer and the histograms are free now): read from global memory inside the j loop, every iteration paid
   //      the L2 latency (30+ us at n = 100).  thread -> (row i, column c), lanes along c ----
-  const int cw0 = blockIdx.x * SM_COLS;
-  const int ncols = min(SM_COLS, d - cw0);
   float* ts = tc;                                    // [n][SM_COLS + 1]
   float* gs = reinterpret_cast<float*>(hist);        // [n][SM_COLS]   (2 * 2048 words >= 128 * 32)
-  for (int e = t; e < n * SM_COLS; e += SM_THREADS) {
-    const int j = e / SM_COLS, cl = e % SM_COLS;
-    const bool ok = cl < ncols;
-    ts[j * (SM_COLS + 1) + cl] = ok ? T[(size_t)j * d + cw0 + cl] : 0.f;
-    gs[j * SM_COLS + cl] = ok ? G[(size_t)j * d + cw0 + cl] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // fetched before the median (below the distance stage), stored now
+    const int e = t + k * SM_THREADS;
+    if (e < n * SM_COLS) {
+      ts[(e / SM_COLS) * (SM_COLS + 1) + e % SM_COLS] = preT[k];
+      gs[e] = preG[k];
+    }
   }
   __syncthreads();
   // A wave owns the rows wave + 16 r (r < RB = ceil(n / 16)); lane -> column (lane & 31) and half of the j range
