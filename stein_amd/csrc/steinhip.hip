@@ -477,16 +477,16 @@ __device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u
 
 // One workgroup: exact weighted selection of the two median targets among the buffered window entries.
 // Entry = key << 2 | weight, offset o = key - lo_key < 65536: pass 1 histograms o >> 8, pass 2 the low byte of the
-// entries that share each target's high byte.
-__global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* sp, const u64* __restrict__ slots,
-                                                      float ln_n, float* h2_out, int update) {
+// entries that share each target's high byte.  Returns (workgroup-uniform) whether the window held both targets.
+__device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, const u64* __restrict__ slots, float ln_n,
+                                                 float* h2_out, int update) {
   const u64* __restrict__ buf = slots + SPEC_SLOTS * 8;
   __shared__ u32 h1[256], h2a[256], h2b[256], scan[256];
   __shared__ u32 sel[8];   // [0,1] high bytes, [2,3] ranks inside them, [4,5] low bytes, [6,7] scratch
   __shared__ u64 below_s;
   const int t = threadIdx.x;
   const u32 cnt = sp->count, lo = sp->lo_key;
-  if (sp->width == 0u || sp->overflow || cnt > SPEC_CAP || cnt == 0u) return;   // miss: the radix passes run
+  if (sp->width == 0u || sp->overflow || cnt > SPEC_CAP || cnt == 0u) return false;   // miss: the radix select runs
   if (t == 0) below_s = 0ull;
   if (t < 256) { h1[t] = 0u; h2a[t] = 0u; h2b[t] = 0u; }
   __syncthreads();
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* s
   __syncthreads();
   const u64 total = sp->total, below = below_s;
   const u64 r0 = (total & 1ull) ? total / 2 : total / 2 - 1, r1 = total / 2;
-  if (r0 < below || r1 - below > 0xfffffff0ull) return;   // the target lies below the window
+  if (r0 < below || r1 - below > 0xfffffff0ull) return false;   // the target lies below the window
   for (u32 i = t; i < cnt; i += 1024) {
     const u64 e = buf[i];
     atomicAdd(&h1[((u32)(e >> 2) - lo) >> 8], (u32)e & 3u);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* s
   spec_locate(h1, (u32)(r0 - below), scan, &sel[0], &sel[2]);
   spec_locate(h1, (u32)(r1 - below), scan, &sel[1], &sel[3]);
   const u32 ba = sel[0], bb = sel[1];
-  if (ba == 256u || bb == 256u) return;   // a target lies above the window
+  if (ba == 256u || bb == 256u) return false;   // a target lies above the window
   for (u32 i = t; i < cnt; i += 1024) {
     const u64 e = buf[i];
     const u32 o = (u32)(e >> 2) - lo, w = (u32)e & 3u;
@@ -524,6 +524,102 @@ __global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* s
     sp->hit = 1u;
     sp->skip_l0 = 1u;
     if (update) spec_update_dev(st, sp);   // fused call: no separate k_spec_update launch
+  }
+  return true;
+}
+
+// Small symmetric blocks (fused call, n <= SOLO_MAX_N): when the window misses, this one workgroup runs the whole
+// 3-level radix select over the upper triangle of D itself (LDS histograms, digits located by a prefix sum over the
+// 2048 bins), so the fused call launches no histogram passes at all -- three launches that, on the usual hit, did
+// nothing for 4-5 us each.  A miss costs ~30 us here instead of ~15 us; misses are the first two steps and jumps.
+constexpr int SOLO_MAX_N = 512;
+__device__ __forceinline__ void solo_locate(const u32* h, u32 rank, u32* wsum, u32* out_bin, u32* out_rest) {
+  // 1024 threads, two bins each; *out_bin / *out_rest are LDS words written by the one thread that finds the rank
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u32 c0 = h[2 * t], c1 = h[2 * t + 1];
+  u32 incl = c0 + c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 base = 0u;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const u32 excl = base + incl - (c0 + c1);
+  if (rank >= excl && rank < excl + c0 + c1) {
+    const u32 b = rank < excl + c0 ? 2u * t : 2u * t + 1u;
+    *out_bin = b;
+    *out_rest = rank - ((b & 1u) ? excl + c0 : excl);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void solo_select(const float* __restrict__ D, long ldD, int n, SelState* st, SpecState* sp,
+                                            float ln_n, float* h2_out) {
+  __shared__ u32 sh[2 * STEIN_HIST_BINS];
+  __shared__ u32 s_wsum[16], s_bin[2], s_rest[2];
+  const int t = threadIdx.x;
+  const long ntc = ldD >> 5;
+  const int ntr = (n + DT_ROWS - 1) / DT_ROWS, nct = (n + DT_COLS - 1) / DT_COLS;
+  const u32 total = (u32)n * (u32)n;
+  u32 prefix[2] = {0u, 0u};
+  u32 rank[2] = {(total & 1u) ? total / 2 : total / 2 - 1, total / 2};
+  bool two = false;
+  for (int level = 0; level < STEIN_HIST_LEVELS; ++level) {
+    const int bits = level == 2 ? 10 : 11, shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    for (int b = t; b < 2 * STEIN_HIST_BINS; b += 1024) sh[b] = 0u;
+    __syncthreads();
+    for (int ti = 0; ti < ntr; ++ti)
+      for (int tj = 0; tj < nct; ++tj) {
+        if (tj * DT_COLS + DT_COLS <= ti * DT_ROWS) continue;   // wholly below the diagonal
+        const float4 v4 = *reinterpret_cast<const float4*>(D + ((size_t)ti * ntc + tj) * DT_ELEMS + t * 4);
+        const int row = ti * DT_ROWS + (t >> 3), c0 = tj * DT_COLS + (t & 7) * 4;
+        const float x[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = c0 + e;
+          if (row < n && col < n && col >= row) {
+            const u32 key = f32_key(x[e]), w = col != row ? 2u : 1u;
+            const u32 digit = (key >> shift) & ((1u << bits) - 1u);
+            const u32 hi = level == 0 ? 0u : key >> (shift + bits);
+            if (level == 0 || hi == prefix[0]) atomicAdd(&sh[digit], w);
+            if (two && hi == prefix[1]) atomicAdd(&sh[STEIN_HIST_BINS + digit], w);
+          }
+        }
+      }
+    __syncthreads();
+    solo_locate(sh, rank[0], s_wsum, &s_bin[0], &s_rest[0]);
+    solo_locate(sh + (two ? STEIN_HIST_BINS : 0), rank[1], s_wsum, &s_bin[1], &s_rest[1]);
+    prefix[0] = (prefix[0] << bits) | s_bin[0];
+    prefix[1] = (prefix[1] << bits) | s_bin[1];
+    rank[0] = s_rest[0];
+    rank[1] = s_rest[1];
+    two = prefix[0] != prefix[1];
+    __syncthreads();   // s_bin / s_rest are rewritten by the next level
+  }
+  if (t == 0) {
+    st->prefix[0] = prefix[0]; st->prefix[1] = prefix[1];
+    st->rank[0] = rank[0]; st->rank[1] = rank[1];
+    st->diverged = two ? 1u : 0u;
+    const float lo = key_f32(prefix[0]), hi = key_f32(prefix[1]);
+    const float med = st->even ? 0.5f * (lo + hi) : lo;
+    const float bw = sqrtf(med / ln_n);      // abstract_kernel.py:40
+    const float h2 = bw * bw;                // squared_exponential_kernel.py:22 squares it again
+    st->lo = lo; st->hi = hi; st->median = med; st->h2 = h2;
+    if (h2_out) *h2_out = h2;
+    spec_update_dev(st, sp);
+  }
+}
+
+// D != NULL ("solo", fused call on a small symmetric block): a miss is resolved here by solo_select
+__global__ __launch_bounds__(1024) void k_spec_select(SelState* st, SpecState* sp, const u64* __restrict__ slots,
+                                                      float ln_n, float* h2_out, int update,
+                                                      const float* __restrict__ D, long ldD, int n) {
+  const bool hit = spec_select_body(st, sp, slots, ln_n, h2_out, update);
+  if (!hit && D) {
+    __syncthreads();
+    solo_select(D, ldD, n, st, sp, ln_n, h2_out);
   }
 }
 
@@ -1385,13 +1481,15 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   STEIN_TSTAMP(STEIN_T_MEDIAN);
   // the window either yields the median now (spec->hit) or the radix-select passes below run; each of them
   // checks the flag on the device, so nothing here waits for the host
+  const bool solo = n <= SOLO_MAX_N;   // small block: a miss is resolved inside k_spec_select, no histogram launches
   hipLaunchKernelGGL(k_spec_select, dim3(1), dim3(1024), 0, s, (SelState*)sel, spec, spec_buf,
-                     (float)log((double)n), h2_out, 1);
+                     (float)log((double)n), h2_out, 1, solo ? (const float*)D : (const float*)nullptr, (long)L.ld_dist,
+                     (int)n);
   LAUNCH_CHECK("k_spec_select");
   // chained radix select: three passes that resolve the earlier levels themselves; the last workgroup of the third
   // resolves the rest.  Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
   const HistFinal fin{(SelState*)sel, spec, h2_out, &fuse->done_hist, (float)log((double)n)};
-  for (int lv = 0; lv < STEIN_HIST_LEVELS; ++lv)
+  for (int lv = 0; lv < (solo ? 0 : STEIN_HIST_LEVELS); ++lv)
     if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit,
                              true, lv == STEIN_HIST_LEVELS - 1 ? fin : HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f})))
       return rc;
