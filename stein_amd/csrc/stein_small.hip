@@ -19,6 +19,24 @@ constexpr int SM_COLS = 32;       // parameter columns per workgroup (their thet
 constexpr int SM_CK = 32;         // columns of theta staged per pass of the distance loop
 static_assert(SM_COLS == SM_CK, "the theta chunk buffer doubles as the phi stage's theta block");
 
+#ifdef STEIN_STAMPS   // diagnostic build only (scratch/small_stamps.py): cycles per phase of workgroup 0
+__device__ unsigned long long g_small_stamps[16];
+extern "C" int stein_debug_small(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#define SST(k)                                                                     \
+  do {                                                                             \
+    __syncthreads();                                                               \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                                     \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+      g_small_stamps[k] = now_ - sst_last;                                         \
+      sst_last = now_;                                                             \
+    }                                                                              \
+  } while (0)
+#else
+#define SST(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restrict__ T, const float* __restrict__ G, int n,
                                                            int d, float ln_n, float* __restrict__ phi,
                                                            float* __restrict__ h2_out, double* __restrict__ sqpart,
@@ -34,6 +52,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   __shared__ float s_h2;
   __shared__ double s_red[SM_THREADS / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef STEIN_STAMPS
+  unsigned long long sst_last = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- S = T T^T, theta staged SM_CK columns at a time.  Thread (bi, bj) = (t / 32, t % 32) owns the entries
   //      (bi + 32 r, bj + 32 s), r, s < R = ceil(n / 32): 2 R LDS reads feed R^2 FMAs per column, the row reads are
@@ -119,6 +140,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     case 3: distances(std::integral_constant<int, 3>()); break;
     default: distances(std::integral_constant<int, 4>()); break;
   }
+  SST(0);   // distances (+ row norms, level-0 histogram)
   // this workgroup's theta / score columns for the phi stage: requested now, so the loads fly during the median
   const int cw0 = blockIdx.x * SM_COLS;
   const int ncols = min(SM_COLS, d - cw0);
@@ -192,6 +214,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     }
     if (t == 0) s_div = s_prefix[0] != s_prefix[1] ? 1u : 0u;
     __syncthreads();
+    SST(1 + level);   // median levels (level 0: locate only)
   }
   if (t == 0) {
     const float lo = key_f32(s_prefix[0]), hi = key_f32(s_prefix[1]);
@@ -202,6 +225,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   }
   __syncthreads();
   const float h2 = s_h2;
+  SST(4);   // bandwidth
   // ---- K in place (exp(-D / h2 / 2) = exp2(kc D), as the tiled kernels form it), rowsum(K): the 32 lanes that share
   //      bi hold 32 columns of a row, so a row's sum is R shuffle reductions, added in a fixed order ----
   const float kc = -1.44269504088896341f / (2.f * h2);
@@ -223,6 +247,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     if (bj == 0 && i < n) rn[i] = s;
   }
   __syncthreads();
+  SST(5);   // K + rowsum
   // ---- phi for this workgroup's SM_COLS columns.  Their theta / score columns are staged in LDS first (the chunk
   //      buffer and the histograms are free now): read from global memory inside the j loop, every iteration paid
   //      the L2 latency (30+ us at n = 100).  thread -> (row i, column c), lanes along c ----
@@ -237,16 +262,19 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     }
   }
   __syncthreads();
-  // A wave owns the rows wave + 16 r (r < RB = ceil(n / 16)); lane -> column (lane & 31) and half of the j range
-  // (lane >> 5).  All RB rows advance together: per four j one 16-byte broadcast read of K per row and the staged score /
+  // A wave owns the rows wave + 16 r (r < RB = ceil(n / 16)).  All RB rows advance together: per four j one 16-byte broadcast read of K per row and the staged score /
   // theta entries once, for 8 RB FMAs -- one row at a time read three words per two FMAs and the stage was bound by LDS
   // bandwidth (61 k of the kernel's 144 k cycles at n = 128).
   double sq = 0.0;
   const float fn = (float)n;
-  const int cl = lane & 31, jh = lane >> 5;
-  const int jmid = min(n, (((n + 1) / 2) + 3) & ~3), j0 = jh ? jmid : 0, j1 = jh ? n : jmid;
-  auto phi_rows = [&](auto rb_tag) {
-    constexpr int RB = decltype(rb_tag)::value;
+  // Lanes: CLW columns x 64 / CLW slices of the j range (slice starts are multiples of 4).  CLW = 32 unless the
+  // workgroup has few columns (d = 1 ... 16: the reference's regression examples), where 32 column lanes would spend
+  // the stage multiplying padding.
+  auto phi_rows = [&](auto rb_tag, auto clw_tag) {
+    constexpr int RB = decltype(rb_tag)::value, CLW = decltype(clw_tag)::value, JS = 64 / CLW;
+    const int cl = lane & (CLW - 1), jh = lane / CLW;
+    const int jq = (((n + JS - 1) / JS) + 3) & ~3;
+    const int j0 = min(n, jh * jq), j1 = min(n, j0 + jq);
     float kg[RB], kt[RB];
     const float* krow[RB];
 #pragma unroll
@@ -281,7 +309,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const float sg = kg[r] + __shfl_xor(kg[r], 32), st = kt[r] + __shfl_xor(kt[r], 32);
+      float sg = kg[r], st = kt[r];
+#pragma unroll
+      for (int o = CLW; o < 64; o <<= 1) { sg += __shfl_xor(sg, o); st += __shfl_xor(st, o); }
       const int i = wave + (SM_THREADS / 64) * r;
       if (jh == 0 && cl < ncols && i < n) {
         const int c = cw0 + cl;
@@ -293,9 +323,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
       }
     }
   };
-  if (n <= 2 * (SM_THREADS / 64)) phi_rows(std::integral_constant<int, 2>());         // workgroup-uniform
-  else if (n <= 4 * (SM_THREADS / 64)) phi_rows(std::integral_constant<int, 4>());
-  else phi_rows(std::integral_constant<int, 8>());
+  auto phi_cols = [&](auto rb_tag) {   // workgroup-uniform choices
+    if (ncols <= 8) phi_rows(rb_tag, std::integral_constant<int, 8>());
+    else if (ncols <= 16) phi_rows(rb_tag, std::integral_constant<int, 16>());
+    else phi_rows(rb_tag, std::integral_constant<int, 32>());
+  };
+  if (n <= 2 * (SM_THREADS / 64)) phi_cols(std::integral_constant<int, 2>());
+  else if (n <= 4 * (SM_THREADS / 64)) phi_cols(std::integral_constant<int, 4>());
+  else phi_cols(std::integral_constant<int, 8>());
+  SST(6);   // stage + phi
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0) s_red[wave] = sq;
