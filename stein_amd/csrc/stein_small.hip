@@ -1,5 +1,5 @@
 // stein_small.hip -- the whole phi computation in ONE kernel for the particle counts the reference's own examples
-// use (n = 20 ... 100): at that size the staged pipeline is ~25 launches of a few microseconds each and nothing
+// use (n = 20 ... 100): at that size the tiled pipeline is about ten launches of a few microseconds each and nothing
 // else.  Every workgroup redundantly computes the row norms, the n x n distance matrix (kept in LDS), its exact
 // median (the same 3-level radix select on the order-preserving key, here on LDS histograms) and K, then forms phi
 // for its own block of SM_COLS parameter columns; one small reduction kernel sums the per-workgroup |phi|^2.
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   const float h2 = s_h2;
   SST(4);   // bandwidth
   // ---- K in place (exp(-D / h2 / 2) = exp2(kc D), as the tiled kernels form it), rowsum(K): the 32 lanes that share
-  //      bi hold 32 columns of a row, so a row's sum is R shuffle reductions, added in a fixed order ----
+  //      bi hold 32 columns of a row, so a row's sum is this thread's R entries plus one shuffle reduction (a fixed order) ----
   const float kc = -1.44269504088896341f / (2.f * h2);
   for (int r = 0; r < R; ++r) {
     const int i = bi + 32 * r;
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
         Dm[i * ldn + j] = k;
         if (K_out && blockIdx.x == 0) K_out[(size_t)i * n + j] = k;
       }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) k += __shfl_xor(k, o);
       s += k;
     }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (bj == 0 && i < n) rn[i] = s;
   }
   __syncthreads();

@@ -1453,7 +1453,8 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     return STEIN_OK;
   }
   // The prologue carries the row norms and all set-up; two kernels let their last workgroup do what a one-workgroup
-  // follow-up launch would (FuseState tickets): twelve launches where the separate stages take sixteen.
+  // follow-up launch would (FuseState tickets): twelve launches where the separate stages take sixteen (nine for
+  // n <= SOLO_MAX_N, where k_spec_select also covers the radix select).
   FuseState* fuse = (FuseState*)((char*)sel + sizeof(SelState) + sizeof(SpecState));
   {
     u32* cmax = nullptr;
