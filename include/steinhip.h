@@ -50,7 +50,7 @@ enum {
                         STEIN_SPLIT_KIND=b3: three bf16 terms, six products); see stein_amd/csrc/stein_x3.hip.
                         bf16 inputs use one bf16 product.  Adds the PLANES section to the workspace. */
   STEIN_FLAG_TIMING = 4, /* stein_svgd_phi only: record a HIP event at every stage boundary (see stein_timing_reserve) */
-  STEIN_FLAG_TILED = 8   /* stein_svgd_phi only: never take the one-kernel path for n <= 128 (stein_small.hip); the
+  STEIN_FLAG_TILED = 8   /* stein_svgd_phi only: never take the one-kernel path for n <= 160 (stein_small.hip); the
                             tiled kernels then also leave D, the histograms and the planes in the workspace */
 };
 /* flags for the staged distance / histogram calls */

@@ -537,7 +537,7 @@ struct SteinLayout {
 };
 int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, SteinLayout* L);
 
-// stein_small.hip: the whole phi computation in one kernel for n <= 128 (the reference's own example sizes)
+// stein_small.hip: the whole phi computation in one kernel for n <= 160 (the reference's own example sizes)
 bool stein_small_ok(int64_t n, int64_t d, int dtype);
 int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
                     double* sqpart /* one partial |phi|^2 per workgroup, *nparts of them (<= ceil(d / 32)) */,

@@ -13,7 +13,8 @@
 
 #include <type_traits>
 
-constexpr int SM_MAXN = 128;      // particles (the distance matrix lives in LDS: 128 x 129 floats = 66 KB)
+constexpr int SM_MAXN = 160;      // particles (the distance matrix lives in LDS: 160 x 160 floats = 100 KB of the CU's 160)
+constexpr int SM_STG = (SM_MAXN * 32 + 1023) / 1024;   // staged entries per thread (5)
 constexpr int SM_THREADS = 1024;
 constexpr int SM_COLS = 32;       // parameter columns per workgroup (their theta / score columns are staged in LDS)
 constexpr int SM_CK = 32;         // columns of theta staged per pass of the distance loop
@@ -82,12 +83,12 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
       pb[r] = tc + min(bj + 32 * r, n - 1) * (SM_CK + 1);
     }
     // the next chunk's theta entries travel from global memory into registers while this chunk is multiplied
-    // (n * SM_CK <= 4 * SM_THREADS entries: at most four per thread)
-    static_assert(SM_MAXN * SM_CK <= 4 * SM_THREADS, "four staged entries per thread");
-    float pre[4];
+    // (n * SM_CK <= SM_STG * SM_THREADS entries: at most SM_STG per thread)
+    static_assert(SM_MAXN * SM_CK <= SM_STG * SM_THREADS, "SM_STG staged entries per thread");
+    float pre[SM_STG];
     auto fetch = [&](int c0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < SM_STG; ++k) {
         const int e = t + k * SM_THREADS, i = e / SM_CK, c = e % SM_CK;
         pre[k] = (e < n * SM_CK && c0 + c < d) ? T[(size_t)i * d + c0 + c] : 0.f;   // zero-filled past d
       }
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     for (int c0 = 0; c0 < d; c0 += SM_CK) {
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < SM_STG; ++k) {
         const int e = t + k * SM_THREADS;
         if (e < n * SM_CK) tc[(e / SM_CK) * (SM_CK + 1) + e % SM_CK] = pre[k];
       }
@@ -138,15 +139,16 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     case 1: distances(std::integral_constant<int, 1>()); break;
     case 2: distances(std::integral_constant<int, 2>()); break;
     case 3: distances(std::integral_constant<int, 3>()); break;
-    default: distances(std::integral_constant<int, 4>()); break;
+    case 4: distances(std::integral_constant<int, 4>()); break;
+    default: distances(std::integral_constant<int, 5>()); break;
   }
   SST(0);   // distances (+ row norms, level-0 histogram)
   // this workgroup's theta / score columns for the phi stage: requested now, so the loads fly during the median
   const int cw0 = blockIdx.x * SM_COLS;
   const int ncols = min(SM_COLS, d - cw0);
-  float preT[4], preG[4];
+  float preT[SM_STG], preG[SM_STG];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < SM_STG; ++k) {
     const int e = t + k * SM_THREADS, j = e / SM_COLS, cl = e % SM_COLS;
     const bool ok = e < n * SM_COLS && cl < ncols;
     preT[k] = ok ? T[(size_t)j * d + cw0 + cl] : 0.f;
@@ -252,9 +254,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   //      buffer and the histograms are free now): read from global memory inside the j loop, every iteration paid
   //      the L2 latency (30+ us at n = 100).  thread -> (row i, column c), lanes along c ----
   float* ts = tc;                                    // [n][SM_COLS + 1]
-  float* gs = reinterpret_cast<float*>(hist);        // [n][SM_COLS]   (2 * 2048 words >= 128 * 32)
+  float* gs = reinterpret_cast<float*>(hist);        // [n][SM_COLS]   (the region is sized for whichever is larger)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {   // fetched before the median (below the distance stage), stored now
+  for (int k = 0; k < SM_STG; ++k) {   // fetched before the median (below the distance stage), stored now
     const int e = t + k * SM_THREADS;
     if (e < n * SM_COLS) {
       ts[(e / SM_COLS) * (SM_COLS + 1) + e % SM_COLS] = preT[k];
@@ -330,7 +332,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
   };
   if (n <= 2 * (SM_THREADS / 64)) phi_cols(std::integral_constant<int, 2>());
   else if (n <= 4 * (SM_THREADS / 64)) phi_cols(std::integral_constant<int, 4>());
-  else phi_cols(std::integral_constant<int, 8>());
+  else if (n <= 8 * (SM_THREADS / 64)) phi_cols(std::integral_constant<int, 8>());
+  else phi_cols(std::integral_constant<int, 10>());
+  static_assert(SM_MAXN <= 10 * (SM_THREADS / 64), "rows per wave");
   SST(6);   // stage + phi
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -347,17 +351,19 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
 // the caller (stein_svgd_phi) checks applicability with stein_small_ok first
 bool stein_small_ok(int64_t n, int64_t d, int dtype) {
   static const bool off = [] { const char* e = getenv("STEIN_SMALL"); return e && e[0] == '0'; }();
-  return !off && dtype == STEIN_F32 && n >= 2 && n <= SM_MAXN && n * n * d <= (4ll << 20) && (d + SM_COLS - 1) / SM_COLS <= 1024;
+  return !off && dtype == STEIN_F32 && n >= 2 && n <= SM_MAXN && n * n * d <= 2200000ll /* measured crossover with the tiled kernels: scratch/small_vs_tiled2.py */ && (d + SM_COLS - 1) / SM_COLS <= 1024;
 }
 
 int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
                     double* sqpart, float* K_out, float* dK_out, int* nparts, double* sqnorm_out, hipStream_t stream) {
   const int blocks = (int)((d + SM_COLS - 1) / SM_COLS);
-  const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + 2 * STEIN_HIST_BINS * sizeof(u32);
+  // distances | theta chunk | rowsum | histograms, later the score block [n][32] (whichever is larger)
+  const size_t hist_b = 2 * STEIN_HIST_BINS * sizeof(u32), gs_b = (size_t)n * SM_COLS * sizeof(float);
+  const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + (hist_b > gs_b ? hist_b : gs_b);
   static bool attr_set = false;
   if (!attr_set) {   // more than the default 64 KB of dynamic LDS
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svgd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                120 * 1024));
+                                150 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_svgd_small, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, theta, score, (int)n, (int)d,

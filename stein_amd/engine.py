@@ -150,7 +150,7 @@ class SvgdEngine:
         if x3 is None:
             x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
         self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
-        # small=False: the fused call never takes the one-kernel path for n <= 128 (tests of the tiled kernels)
+        # small=False: the fused call never takes the one-kernel path for n <= 160 (tests of the tiled kernels)
         self.flags = (_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED)
         # several ranks: use the speculative median window (one 512 KB all-reduce and a hit-flag read-back per step
         # instead of two passes over the local distance block) when the block is large enough for that to pay

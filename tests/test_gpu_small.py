@@ -1,4 +1,4 @@
-"""GPU: the one-kernel path of the fused call for n <= 128 (csrc/stein_small.hip) -- the particle counts of the
+"""GPU: the one-kernel path of the fused call for n <= 160 (csrc/stein_small.hip) -- the particle counts of the
 reference's own examples -- against the fp64/fp32 oracle, against the tiled kernels, and for its K / dK outputs."""
 import numpy as np
 import pytest
@@ -9,7 +9,8 @@ from stein_amd.engine import SvgdEngine
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(2, 1), (3, 2), (7, 3), (8, 5), (20, 303), (50, 1), (100, 10), (100, 55), (127, 130), (128, 64), (64, 1000)]
+SHAPES = [(2, 1), (3, 2), (7, 3), (8, 5), (20, 303), (50, 1), (100, 10), (100, 55), (127, 130), (128, 64), (64, 1000),
+          (129, 3), (150, 40), (160, 64), (160, 160)]   # n^2 d > 2.2e6 (64x1000, 160x160) runs the tiled kernels
 
 
 @pytest.mark.parametrize("n,d", SHAPES)
@@ -37,7 +38,7 @@ def test_small_path_matches_oracle_and_tiled_kernels(cuda, n, d):
 
 @pytest.mark.skipif(__import__("os").environ.get("STEIN_SMALL", "") == "0", reason="STEIN_SMALL=0 disables the path under test")
 def test_small_path_is_taken_and_left(cuda):
-    """n <= 128 takes the one-kernel path (the workspace's distance image stays untouched); larger n or small=False do not."""
+    """n <= 160 takes the one-kernel path (the workspace's distance image stays untouched); larger n or small=False do not."""
     n, d = 64, 8
     T = torch.randn(n, d, device=cuda)
     G = torch.randn(n, d, device=cuda)
