@@ -17,8 +17,15 @@ constexpr int SM_MAXN = 160;      // particles (the distance matrix lives in LDS
 constexpr int SM_STG = (SM_MAXN * 32 + 1023) / 1024;   // staged entries per thread (5)
 constexpr int SM_THREADS = 1024;
 constexpr int SM_COLS = 32;       // parameter columns per workgroup (their theta / score columns are staged in LDS)
-constexpr int SM_CK = 32;         // columns of theta staged per pass of the distance loop
+constexpr int SM_CK = 32;         // granule of the theta chunk staged per pass of the distance loop: a chunk is `ck` columns,
+                                  // the multiple of 32 (<= 256) for which n * ck entries still fit SM_STG registers per thread
 static_assert(SM_COLS == SM_CK, "the theta chunk buffer doubles as the phi stage's theta block");
+static inline int small_chunk(int64_t n, int64_t d) {
+  int64_t ck = (int64_t)SM_STG * SM_THREADS / n / SM_CK * SM_CK;
+  ck = ck < SM_CK ? SM_CK : (ck > 256 ? 256 : ck);
+  const int64_t dr = (d + SM_CK - 1) / SM_CK * SM_CK;   // no wider than the matrix
+  return (int)(ck < dr ? ck : dr);
+}
 
 #ifdef STEIN_STAMPS   // diagnostic build only (scratch/small_stamps.py): cycles per phase of workgroup 0
 __device__ unsigned long long g_small_stamps[16];
@@ -42,12 +49,12 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
                                                            int d, float ln_n, float* __restrict__ phi,
                                                            float* __restrict__ h2_out, double* __restrict__ sqpart,
                                                            float* __restrict__ K_out, float* __restrict__ dK_out,
-                                                           double* __restrict__ sq_total) {
+                                                           double* __restrict__ sq_total, int ck) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ldn = (n + 3) & ~3;   // rows start 16-byte aligned (the phi stage reads K four columns at a time)
   float* Dm = sm;                                   // [n][ldn]  distances, then K
-  float* tc = Dm + (size_t)n * ldn;                 // [n][SM_CK + 1] theta chunk
-  float* rn = tc + (size_t)n * (SM_CK + 1);         // [n] row norms, later rowsum(K)
+  float* tc = Dm + (size_t)n * ldn;                 // [n][ck + 1] theta chunk
+  float* rn = tc + (size_t)n * (ck + 1);            // [n] rowsum(K)
   u32* hist = reinterpret_cast<u32*>(rn + n);       // [2][2048]
   __shared__ u32 s_prefix[2], s_rank[2], s_div, s_wsum[SM_THREADS / 64];
   __shared__ float s_h2;
@@ -79,32 +86,32 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
     const float* pb[RR];
 #pragma unroll
     for (int r = 0; r < RR; ++r) {   // rows past n read row n - 1 (harmless, never stored)
-      pa[r] = tc + min(bi + 32 * r, n - 1) * (SM_CK + 1);
-      pb[r] = tc + min(bj + 32 * r, n - 1) * (SM_CK + 1);
+      pa[r] = tc + min(bi + 32 * r, n - 1) * (ck + 1);
+      pb[r] = tc + min(bj + 32 * r, n - 1) * (ck + 1);
     }
     // the next chunk's theta entries travel from global memory into registers while this chunk is multiplied
-    // (n * SM_CK <= SM_STG * SM_THREADS entries: at most SM_STG per thread)
+    // (n * ck <= SM_STG * SM_THREADS entries: at most SM_STG per thread -- small_chunk())
     static_assert(SM_MAXN * SM_CK <= SM_STG * SM_THREADS, "SM_STG staged entries per thread");
     float pre[SM_STG];
     auto fetch = [&](int c0) {
 #pragma unroll
       for (int k = 0; k < SM_STG; ++k) {
-        const int e = t + k * SM_THREADS, i = e / SM_CK, c = e % SM_CK;
-        pre[k] = (e < n * SM_CK && c0 + c < d) ? T[(size_t)i * d + c0 + c] : 0.f;   // zero-filled past d
+        const int e = t + k * SM_THREADS, i = e / ck, c = e - i * ck;
+        pre[k] = (e < n * ck && c0 + c < d) ? T[(size_t)i * d + c0 + c] : 0.f;   // zero-filled past d
       }
     };
     fetch(0);
-    for (int c0 = 0; c0 < d; c0 += SM_CK) {
+    for (int c0 = 0; c0 < d; c0 += ck) {
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < SM_STG; ++k) {
         const int e = t + k * SM_THREADS;
-        if (e < n * SM_CK) tc[(e / SM_CK) * (SM_CK + 1) + e % SM_CK] = pre[k];
+        if (e < n * ck) tc[e + e / ck] = pre[k];   // row e / ck, column e % ck, row stride ck + 1
       }
-      if (c0 + SM_CK < d) fetch(c0 + SM_CK);
+      if (c0 + ck < d) fetch(c0 + ck);
       __syncthreads();
       if (mine) {
-        const int cend = min(SM_CK, d - c0);
+        const int cend = min(ck, d - c0);
 #pragma unroll 8
         for (int c = 0; c < cend; ++c) {
           float a[RR], b[RR];
@@ -359,7 +366,7 @@ int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d
   const int blocks = (int)((d + SM_COLS - 1) / SM_COLS);
   // distances | theta chunk | rowsum | histograms, later the score block [n][32] (whichever is larger)
   const size_t hist_b = 2 * STEIN_HIST_BINS * sizeof(u32), gs_b = (size_t)n * SM_COLS * sizeof(float);
-  const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (SM_CK + 1) + n) * sizeof(float) + (hist_b > gs_b ? hist_b : gs_b);
+  const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (small_chunk(n, d) + 1) + n) * sizeof(float) + (hist_b > gs_b ? hist_b : gs_b);
   static bool attr_set = false;
   if (!attr_set) {   // more than the default 64 KB of dynamic LDS
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svgd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -367,7 +374,7 @@ int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d
     attr_set = true;
   }
   hipLaunchKernelGGL(k_svgd_small, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, theta, score, (int)n, (int)d,
-                     (float)log((double)n), phi, h2_out, sqpart, K_out, dK_out, sqnorm_out);
+                     (float)log((double)n), phi, h2_out, sqpart, K_out, dK_out, sqnorm_out, small_chunk(n, d));
   LAUNCH_CHECK("k_svgd_small");
   *nparts = blocks == 1 ? 0 : blocks;   // one workgroup: it has written *sqnorm_out itself
   return STEIN_OK;
