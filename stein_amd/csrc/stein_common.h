@@ -242,9 +242,9 @@ struct SpecCtx {   // per-thread view of the speculative window (SPEC epilogues 
 };
 
 template <bool MIRROR, bool PRED, bool DIAG, bool HIST, bool SPEC>
-__device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, const float* __restrict__ r,
-                                                       float* __restrict__ D, int n, int row0, int n_local, long ldD,
-                                                       int tile_m, int brow0, u32 base, u64& packed, float two_s,
+__device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, float* __restrict__ D, int n,
+                                                       int n_local, long ldD, int tile_m, int brow0, u32 base,
+                                                       u64& packed, float two_s,
                                                        SpecCtx& sx, const float* rr, const float* rc, int i,
                                                        float* __restrict__ stage) {
   // One call handles acc[i][*]: rows wy*64 + i*32 .. +31 of the tile, the wave's 64 columns.
@@ -378,9 +378,9 @@ __device__ __forceinline__ EpiPrefetch distance_epilogue_prefetch(const float* _
 // their last LDS read): half-tile staging, 8 KB histogram, counters, window queue, row / column norms.
 // spec != NULL needs hist0 != NULL.
 template <bool SYM>
-__device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* lds, const float* __restrict__ r,
-                                                  float* __restrict__ D, int n, int row0, int n_local, long ldD,
-                                                  int tile_m, int tile_n, u64* __restrict__ hist0,
+__device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* lds, float* __restrict__ D, int n,
+                                                  int n_local, long ldD, int tile_m, int tile_n,
+                                                  u64* __restrict__ hist0,
                                                   const EpiPrefetch& pf, float two_s = 2.f,
                                                   SpecState* __restrict__ spec = nullptr,
                                                   u64* __restrict__ spec_buf = nullptr) {
@@ -424,13 +424,13 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
 #define STEIN_EPI_I(MIRROR, PRED, DIAG, I)                                                                             \
   do {                                                                                                                 \
     if (window)                                                                                                        \
-      distance_epilogue_body<MIRROR, PRED, DIAG, false, true>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
+      distance_epilogue_body<MIRROR, PRED, DIAG, false, true>(acc, hl, D, n, n_local, ldD, tile_m, brow0,             \
                                                               base, packed, two_s, sx, rr, rc, I, stage);             \
     else if (hist)                                                                                                     \
-      distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,    \
+      distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, D, n, n_local, ldD, tile_m, brow0,             \
                                                               base, packed, two_s, sx, rr, rc, I, stage);             \
     else                                                                                                               \
-      distance_epilogue_body<MIRROR, PRED, DIAG, false, false>(acc, hl, r, D, n, row0, n_local, ldD, tile_m, brow0,   \
+      distance_epilogue_body<MIRROR, PRED, DIAG, false, false>(acc, hl, D, n, n_local, ldD, tile_m, brow0,            \
                                                                base, packed, two_s, sx, rr, rc, I, stage);            \
   } while (0)
   const long ntc = ldD >> 5;

@@ -83,7 +83,6 @@ extern "C" int stein_debug_stamps(u64* host_out, int reset) {
 
 constexpr int XROW = 64;                 // bytes per LDS row: 32 bf16
 constexpr int XPLANE = 128 * XROW;       // one 128-row plane of a tile: 8192 B
-constexpr int XOPER = 3 * XPLANE;        // three planes of one operand tile: 24576 B
 constexpr int XTILE_E = 128 * 32;        // elements of one plane of a tile
 __device__ __forceinline__ int xswz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
 // Vt3 plane, element offset of 16-byte chunk `chunk` (8 consecutive k starting at 8 chunk) of row `row` (0..127):
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const
                                                u16* __restrict__ Tt1, int dc, long nk, const float* __restrict__ sc,
                                                int zbase) {
   const bool score = blockIdx.z + zbase != 0;
-  if (score && (blockIdx.x * 64 >= dc || (long)blockIdx.y * 64 >= nk)) return;
+  if (score && ((int)blockIdx.x * 64 >= dc || (long)blockIdx.y * 64 >= nk)) return;
   const TIN* __restrict__ X = score ? X1 : X0;
   u16* __restrict__ R = score ? nullptr : R0;
   u16* __restrict__ Tt = score ? Tt1 : Tt0;
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
     __syncthreads();
     STAMP(1);
   }
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, pf,
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
                          two_s_v, spec, spec_buf);
 #ifdef STEIN_STAMPS
   STAMP(3);     // epilogue

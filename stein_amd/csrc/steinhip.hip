@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
   }
 
   // the staging tiles are dead (every wave is past the loop's last barrier): 8 KB of them hold the level-0 histogram
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), r, D, n, row0, n_local, ldD, tile_m, tile_n, hist0, pf, 2.f,
+  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf, 2.f,
                          spec, spec_buf);
 }
 
