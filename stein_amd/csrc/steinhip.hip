@@ -15,6 +15,7 @@
 // Everything is launched on the caller's stream; nothing here synchronises with the host.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -974,15 +975,43 @@ template <typename S>
 __global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, const float* __restrict__ phi,
                                                        S* __restrict__ hist, long count, const double* sq,
                                                        double host_scale, double thr, double lr, double alpha,
-                                                       double eps, int first, S* __restrict__ step_out) {
-  const double scale = clip_scale_of(sq, host_scale, thr);
+                                                       double eps, int first, S* __restrict__ step_out, int vec) {
+  // arithmetic in the storage type: fp64 state -> fp64 (the reference's NumPy arithmetic), fp32 state -> fp32 (the
+  // results are rounded to fp32 anyway, and the fp64 square root and division made the kernel compute-bound: 25 us
+  // for 80 MB at C3)
+  typedef typename std::conditional<sizeof(S) == 4, float, double>::type C;
+  const C scale = (C)clip_scale_of(sq, host_scale, thr);
+  const C a = (C)alpha, na = (C)(1.0 - alpha), ep = (C)eps, l = (C)lr;
+  if (sizeof(S) == 4 && vec) {   // host: count % 4 == 0, theta present, every pointer 16-byte aligned, no step_out
+    float4* th4 = reinterpret_cast<float4*>(theta);
+    float4* hi4 = reinterpret_cast<float4*>(hist);
+    const float4* ph4 = reinterpret_cast<const float4*>(phi);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < (count >> 2); q += (long)gridDim.x * 256) {
+      const float4 pv = ph4[q], hv = hi4[q];
+      float4 tv = th4[q], ho;
+      const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, hh[4] = {hv.x, hv.y, hv.z, hv.w};
+      float tt[4] = {tv.x, tv.y, tv.z, tv.w}, oo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float p = pp[k] * (float)scale;
+        const float hs = first ? p * p : (float)a * hh[k] + (float)na * p * p;
+        oo[k] = hs;
+        tt[k] += p / ((float)ep + sqrtf(hs)) * (float)l;
+      }
+      ho = make_float4(oo[0], oo[1], oo[2], oo[3]);
+      tv = make_float4(tt[0], tt[1], tt[2], tt[3]);
+      hi4[q] = ho;
+      th4[q] = tv;
+    }
+    return;
+  }
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256) {
-    const double p = (double)phi[e] * scale;
-    const double hs = first ? p * p : alpha * (double)hist[e] + (1.0 - alpha) * p * p;
+    const C p = (C)phi[e] * scale;
+    const C hs = first ? p * p : a * (C)hist[e] + na * p * p;
     hist[e] = (S)hs;
-    const double step = p / (eps + sqrt(hs)) * lr;
+    const C step = p / (ep + sqrt(hs)) * l;
     if (step_out) step_out[e] = (S)step;
-    if (theta) theta[e] = (S)((double)theta[e] + step);
+    if (theta) theta[e] = (S)((C)theta[e] + step);
   }
 }
 
@@ -992,16 +1021,19 @@ __global__ __launch_bounds__(256) void k_apply_adam(S* __restrict__ theta, const
                                                     const double* sq, double host_scale, double thr, double lr,
                                                     double b1, double b2, double eps, int first, double corr1,
                                                     double corr2, S* __restrict__ step_out) {
-  const double scale = clip_scale_of(sq, host_scale, thr);
+  typedef typename std::conditional<sizeof(S) == 4, float, double>::type C;   // as in k_apply_adagrad
+  const C scale = (C)clip_scale_of(sq, host_scale, thr);
+  const C c1 = (C)b1, n1 = (C)(1.0 - b1), c2 = (C)b2, n2 = (C)(1.0 - b2), ep = (C)eps, l = (C)lr;
+  const C k1 = (C)corr1, k2 = (C)corr2;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256) {
-    const double p = (double)phi[e] * scale;
-    const double m = first ? p : b1 * (double)mu[e] + (1.0 - b1) * p;
-    const double v = first ? p * p : b2 * (double)nu[e] + (1.0 - b2) * p * p;
+    const C p = (C)phi[e] * scale;
+    const C m = first ? p : c1 * (C)mu[e] + n1 * p;
+    const C v = first ? p * p : c2 * (C)nu[e] + n2 * p * p;
     mu[e] = (S)m;
     nu[e] = (S)v;
-    const double step = (m / corr1) / (eps + sqrt(v / corr2)) * lr;
+    const C step = (m / k1) / (ep + sqrt(v / k2)) * l;
     if (step_out) step_out[e] = (S)step;
-    if (theta) theta[e] = (S)((double)theta[e] + step);
+    if (theta) theta[e] = (S)((C)theta[e] + step);
   }
 }
 
@@ -1540,8 +1572,10 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
 template <typename S>
 static int apply_adagrad_t(void* theta, const float* phi, void* hist, int64_t count, const double* sq, double hs,
                            double thr, double lr, double alpha, double eps, int first, void* step_out, void* stream) {
-  hipLaunchKernelGGL(k_apply_adagrad<S>, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, (S*)theta,
-                     phi, (S*)hist, (long)count, sq, hs, thr, lr, alpha, eps, first, (S*)step_out);
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+  const int vec = sizeof(S) == 4 && count % 4 == 0 && theta && !step_out && al16(theta) && al16(phi) && al16(hist);
+  hipLaunchKernelGGL(k_apply_adagrad<S>, dim3(grid_for(vec ? count / 4 : count, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (S*)theta, phi, (S*)hist, (long)count, sq, hs, thr, lr, alpha, eps, first, (S*)step_out, vec);
   LAUNCH_CHECK("k_apply_adagrad");
   return STEIN_OK;
 }
