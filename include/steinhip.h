@@ -230,7 +230,8 @@ int stein_timing_read(float* ms_out, int max_calls, int* calls_out);
  *   theta       : [count] of state_dtype, updated in place; may be NULL (state + step_out only:
  *                 this is `gd.update(phi)` on its own)
  *   step_out    : optional [count] of state_dtype, receives the step
- *   state_dtype : STEIN_F32 or STEIN_F64 for theta / optimizer state / step_out (phi is float)
+ *   state_dtype : STEIN_F32 or STEIN_F64 for theta / optimizer state / step_out (phi is float); the map is
+ *                 evaluated in that type (STEIN_F64 = the reference's NumPy float64 arithmetic)
  * Adagrad: stein/optimizers/adagrad_gradient_descent.py:37-44 (first_step -> hist = phi^2).
  * Adam   : stein/optimizers/adam_gradient_descent.py:45-58 (t = n_iters AFTER increment;
  *          t == 1 -> mu = phi, nu = phi^2); the caller multiplies lr by decay afterwards.
