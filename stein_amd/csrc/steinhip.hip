@@ -971,6 +971,17 @@ __device__ __forceinline__ double clip_scale_of(const double* sq, double host_sc
   return thr / (nrm > thr ? nrm : thr);
 }
 
+// one element of the Adagrad map (adagrad_gradient_descent.py:37-44), the same instruction sequence on every path
+// (no compiler-chosen fma contraction: the 16-byte and the scalar loops must agree to the last bit)
+template <typename C>
+__device__ __forceinline__ C adagrad_elem(C p, C h, int first, C a, C na, C ep, C l, C* hs_out) {
+#pragma clang fp contract(off)
+  const C pp = p * p;
+  const C hs = first ? pp : a * h + na * pp;
+  *hs_out = hs;
+  return p / (ep + sqrt(hs)) * l;
+}
+
 template <typename S>
 __global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, const float* __restrict__ phi,
                                                        S* __restrict__ hist, long count, const double* sq,
@@ -993,10 +1004,10 @@ __global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, co
       float tt[4] = {tv.x, tv.y, tv.z, tv.w}, oo[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float p = pp[k] * (float)scale;
-        const float hs = first ? p * p : (float)a * hh[k] + (float)na * p * p;
+        float hs;
+        const float step = adagrad_elem<float>(pp[k] * (float)scale, hh[k], first, (float)a, (float)na, (float)ep, (float)l, &hs);
         oo[k] = hs;
-        tt[k] += p / ((float)ep + sqrtf(hs)) * (float)l;
+        tt[k] = tt[k] + step;
       }
       ho = make_float4(oo[0], oo[1], oo[2], oo[3]);
       tv = make_float4(tt[0], tt[1], tt[2], tt[3]);
@@ -1006,10 +1017,9 @@ __global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, co
     return;
   }
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long)gridDim.x * 256) {
-    const C p = (C)phi[e] * scale;
-    const C hs = first ? p * p : a * (C)hist[e] + na * p * p;
+    C hs;
+    const C step = adagrad_elem<C>((C)phi[e] * scale, (C)hist[e], first, a, na, ep, l, &hs);
     hist[e] = (S)hs;
-    const C step = p / (ep + sqrt(hs)) * l;
     if (step_out) step_out[e] = (S)step;
     if (theta) theta[e] = (S)((C)theta[e] + step);
   }

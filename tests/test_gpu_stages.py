@@ -183,3 +183,38 @@ def test_identical_particles_are_nan_like_reference(cuda):
     torch.cuda.synchronize()
     assert eng.median.item() == 0.0
     assert not torch.isfinite(phi).all()
+
+
+def test_unaligned_outputs_take_the_scalar_paths(cuda):
+    """k_phi_finish and the Adagrad apply use 16-byte accesses only when every pointer allows it; a caller's 4-byte
+    aligned phi / dK / theta / state must give the same values through the scalar loops (include/steinhip.h makes
+    no alignment demand on them)."""
+    import ctypes
+    n, d = 300, 64
+    T64, G64 = _inputs(n, d, seed=11)
+    T = torch.tensor(T64, dtype=torch.float32, device=cuda)
+    G = torch.tensor(G64, dtype=torch.float32, device=cuda)
+    eng = SvgdEngine(n, d, device=cuda, small=False)
+    _staged(eng, T, G)
+    phi_ref, sq_ref = eng.phi.clone(), eng.sqnorm.clone()
+    buf = torch.zeros(n * d + 1, dtype=torch.float32, device=cuda)
+    dkb = torch.zeros(n * d + 1, dtype=torch.float32, device=cuda)
+    phi_un, dk_un = buf[1:].view(n, d), dkb[1:].view(n, d)          # 4 bytes past a 16-byte boundary
+    assert phi_un.data_ptr() % 16 == 4
+    eng.stages.contract_finish(T, n, d, 0, n, eng.h2, phi_un, eng.sqnorm, dk_un, eng.ws, eng.flags)
+    torch.cuda.synchronize()
+    assert torch.equal(phi_un, phi_ref)
+    assert abs(float(eng.sqnorm) - float(sq_ref)) <= 1e-12 * float(sq_ref)
+
+    def apply(theta, phi, hist):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(cuda).cuda_stream)
+        _lib.call("stein_apply_adagrad", ctypes.c_void_p(theta.data_ptr()), ctypes.c_void_p(phi.data_ptr()),
+                  ctypes.c_void_p(hist.data_ptr()), theta.numel(), _lib.F32, None, 1.0, 10.0, 1e-2, 0.9, 1e-6, 0, None, stream)
+    th_a, hi_a = T.clone(), torch.rand(n, d, device=cuda)
+    tb, hb = torch.zeros(n * d + 1, device=cuda), torch.zeros(n * d + 1, device=cuda)
+    th_u, hi_u = tb[1:].view(n, d), hb[1:].view(n, d)
+    th_u.copy_(th_a); hi_u.copy_(hi_a)
+    apply(th_a, phi_ref, hi_a)
+    apply(th_u, phi_ref, hi_u)
+    torch.cuda.synchronize()
+    assert torch.equal(th_a, th_u) and torch.equal(hi_a, hi_u)
