@@ -177,7 +177,7 @@ def cpu_baseline(wl, T64, G64, rows):
 
 
 # products per fp32 operand pair in the split path (stein_x3.hip: KIND 2 -> 3 fp16 products, KIND 3 -> 6 bf16 products)
-NPROD = 6 if os.environ.get("STEIN_SPLIT_KIND", "").startswith("b3") else 3
+NPROD = 3
 
 
 def pmc_traffic(workload_key, x3):

@@ -46,12 +46,14 @@ enum { STEIN_F32 = 0, STEIN_BF16 = 1, STEIN_F64 = 2 };
 enum {
   STEIN_FLAG_NONE = 0,
   STEIN_FLAG_X3 = 1, /* run both GEMMs on the 16-bit matrix cores at fp32-level accuracy: every fp32 operand is scaled
-                        by a power of two and split into two fp16 terms, three products per pair (environment
-                        STEIN_SPLIT_KIND=b3: three bf16 terms, six products); see stein_amd/csrc/stein_x3.hip.
-                        bf16 inputs use one bf16 product.  Adds the PLANES section to the workspace. */
+                        by a power of two and split into two fp16 terms, three products per pair; see
+                        stein_amd/csrc/stein_x3.hip.  bf16 inputs use one bf16 product.  Adds the PLANES section to
+                        the workspace. */
   STEIN_FLAG_TIMING = 4, /* stein_svgd_phi only: record a HIP event at every stage boundary (see stein_timing_reserve) */
-  STEIN_FLAG_TILED = 8   /* stein_svgd_phi only: never take the one-kernel path for n <= 160 (stein_small.hip); the
+  STEIN_FLAG_TILED = 8,  /* stein_svgd_phi only: never take the one-kernel path for n <= 160 (stein_small.hip); the
                             tiled kernels then also leave D, the histograms and the planes in the workspace */
+  STEIN_FLAG_NO_WINDOW = 16 /* stein_svgd_phi only: never grant the speculative median window, i.e. run the radix-select
+                               passes over D on every call (same result; what a window miss costs, for measurements) */
 };
 /* flags for the staged distance / histogram calls */
 enum {
@@ -207,7 +209,8 @@ int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t r
                           void* workspace, size_t ws_bytes, int flags /* same STEIN_FLAG_* as the partial */,
                           void* stream);
 
-/* Stage timing of the fused call (profiling aid; process-global, not thread-safe).  stein_timing_reserve(calls)
+/* Stage timing of the fused call (profiling aid; the events belong to the calling thread, like the last-error string:
+ * reserve, call and read from one thread).  stein_timing_reserve(calls)
  * creates the HIP events for `calls` fused calls and rewinds the cursor; each stein_svgd_phi call made with
  * STEIN_FLAG_TIMING then records an event at every stage boundary on its stream while reserved slots last.
  * stein_timing_read waits for the recorded events and returns the stage durations in milliseconds,
@@ -230,17 +233,19 @@ int stein_timing_read(float* ms_out, int max_calls, int* calls_out);
  *   theta       : [count] of state_dtype, updated in place; may be NULL (state + step_out only:
  *                 this is `gd.update(phi)` on its own)
  *   step_out    : optional [count] of state_dtype, receives the step
- *   state_dtype : STEIN_F32 or STEIN_F64 for theta / optimizer state / step_out (phi is float); the map is
- *                 evaluated in that type (STEIN_F64 = the reference's NumPy float64 arithmetic)
+ *   state_dtype : STEIN_F32 or STEIN_F64 for theta / optimizer state / step_out; the map is evaluated in that type
+ *                 (STEIN_F64 = the reference's NumPy float64 arithmetic)
+ *   phi_dtype   : STEIN_F32 (what stein_svgd_phi produces) or, with STEIN_F64 state only, STEIN_F64: `gd.update(phi)`
+ *                 on a float64 array then is the reference's pure-fp64 map, phi is not rounded to fp32 first
  * Adagrad: stein/optimizers/adagrad_gradient_descent.py:37-44 (first_step -> hist = phi^2).
  * Adam   : stein/optimizers/adam_gradient_descent.py:45-58 (t = n_iters AFTER increment;
  *          t == 1 -> mu = phi, nu = phi^2); the caller multiplies lr by decay afterwards.
  */
-int stein_apply_adagrad(void* theta, const float* phi, void* hist, int64_t count, int state_dtype,
+int stein_apply_adagrad(void* theta, const void* phi, int phi_dtype, void* hist, int64_t count, int state_dtype,
                         const double* sqnorm_dev, double clip_scale_host, double clip_threshold,
                         double lr, double alpha, double eps, int first_step,
                         void* step_out, void* stream);
-int stein_apply_adam(void* theta, const float* phi, void* mu, void* nu, int64_t count, int state_dtype,
+int stein_apply_adam(void* theta, const void* phi, int phi_dtype, void* mu, void* nu, int64_t count, int state_dtype,
                      const double* sqnorm_dev, double clip_scale_host, double clip_threshold,
                      double lr, double beta1, double beta2, double eps, int64_t t,
                      void* step_out, void* stream);

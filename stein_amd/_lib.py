@@ -22,10 +22,13 @@ STAGE_SYMMETRIC = 1
 FLAG_X3 = 1
 FLAG_TIMING = 4
 FLAG_TILED = 8
+FLAG_NO_WINDOW = 16
 GLM_LINEAR, GLM_LOGISTIC = 0, 1
 SPEC_TABLE_WORDS = 65544          # uint64 words of the rank-summed window table ...
 SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC section (slots + entry buffer)
 SPEC_HIT_OFFSET, SPEC_SKIP_L0_OFFSET = 64 + 28, 64 + 52   # uint32 state words inside the SELECT section
+SPEC_NSTEPS_OFFSET, SPEC_NHITS_OFFSET = 64 + 56, 64 + 60   # medians recorded since the predictor started / window hits
+SELECT_BYTES = 192                                        # SelState + SpecState + FuseState
 T_STAGES = ("prepare", "distance", "median", "contract", "finish")   # STEIN_T_* of include/steinhip.h
 
 _c = ctypes
@@ -55,8 +58,8 @@ _SIGNATURES = {
     "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "stein_contract_partial": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp],
     "stein_contract_finish": [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
-    "stein_apply_adagrad": [_vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp],
-    "stein_apply_adam": [_vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],
+    "stein_apply_adagrad": [_vp, _vp, _int, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp],
+    "stein_apply_adam": [_vp, _vp, _int, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],
     "stein_cast_f64_to_f32": [_vp, _vp, _i64, _vp],
     "stein_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
@@ -100,6 +103,21 @@ def check(rc):
 
 def call(name, *args):
     check(getattr(load(), name)(*args))
+
+
+def call_on(device, name, *args):
+    """`call` with `device` (a torch.device of type cuda) as the process's current HIP device for its duration.
+
+    The library launches on the caller's stream; stream 0 and kernel attributes belong to the CURRENT device, so a
+    tensor on cuda:1 handed over while cuda:0 is current would be launched on the wrong GPU.  The common case (the
+    tensor's device is already current) costs one integer comparison.
+    """
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx == torch.cuda.current_device():
+        return call(name, *args)
+    with torch.cuda.device(idx):
+        return call(name, *args)
 
 
 def workspace_layout(n_local, n, d, dtype=F32, flags=0):

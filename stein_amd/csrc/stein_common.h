@@ -125,7 +125,8 @@ struct SpecState {
   u64 total;      // n * n
   u32 last_key;   // key of the previous step's lower median target
   u32 skip_l0;    // the level-0 histogram pass over D is not needed (taken in the distance epilogue, or the window hit)
-  u64 pad;
+  u32 n_steps;    // medians recorded since the predictor started (spec_update_dev) ...
+  u32 n_hits;     // ... and how many of them came from the window: the hit rate a harness reports (bench.py)
 };
 static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
 // Third 64-byte block of the SELECT section (fused call only): "last workgroup out" tickets that let a kernel's last

@@ -357,8 +357,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_svgd_small(const float* __restri
 
 // the caller (stein_svgd_phi) checks applicability with stein_small_ok first
 bool stein_small_ok(int64_t n, int64_t d, int dtype) {
-  static const bool off = [] { const char* e = getenv("STEIN_SMALL"); return e && e[0] == '0'; }();
-  return !off && dtype == STEIN_F32 && n >= 2 && n <= SM_MAXN && n * n * d <= 2200000ll /* measured crossover with the tiled kernels: scratch/small_vs_tiled2.py */ && (d + SM_COLS - 1) / SM_COLS <= 1024;
+  return dtype == STEIN_F32 && n >= 2 && n <= SM_MAXN && n * n * d <= 2200000ll /* measured crossover with the tiled kernels: scratch/small_vs_tiled2.py */ && (d + SM_COLS - 1) / SM_COLS <= 1024;
 }
 
 int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d, float* phi, float* h2_out,
@@ -367,11 +366,15 @@ int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d
   // distances | theta chunk | rowsum | histograms, later the score block [n][32] (whichever is larger)
   const size_t hist_b = 2 * STEIN_HIST_BINS * sizeof(u32), gs_b = (size_t)n * SM_COLS * sizeof(float);
   const size_t lds = ((size_t)n * ((n + 3) & ~(int64_t)3) + (size_t)n * (small_chunk(n, d) + 1) + n) * sizeof(float) + (hist_b > gs_b ? hist_b : gs_b);
-  static bool attr_set = false;
-  if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+  // more than the default 64 KB of dynamic LDS: the attribute belongs to the function ON ONE DEVICE, so it is set once per
+  // device the library launches on (a flag per device id; racing threads at worst set it twice)
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svgd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 150 * 1024));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(k_svgd_small, dim3((unsigned)blocks), dim3(SM_THREADS), lds, stream, theta, score, (int)n, (int)d,
                      (float)log((double)n), phi, h2_out, sqpart, K_out, dK_out, sqnorm_out, small_chunk(n, d));

@@ -2,9 +2,8 @@
 #pragma once
 #include "stein_common.h"
 
-// dtype = STEIN_F32: fp32 inputs, two fp16 planes, three products (or three bf16 planes, six products, when
-// STEIN_SPLIT_KIND=b3); STEIN_BF16: bf16 inputs, one plane, one product
-int stein_x3_kind(int dtype);   // 1, 2 or 3
+// dtype = STEIN_F32: fp32 inputs, two fp16 planes, three products; STEIN_BF16: bf16 inputs, one plane, one product
+int stein_x3_kind(int dtype);   // 1 or 2
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d, const SteinLayout& L,
                    char* planes, hipStream_t stream, u32* fuse_done = nullptr);
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,

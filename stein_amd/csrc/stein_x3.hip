@@ -3,15 +3,15 @@
 // gfx950 runs the 16-bit-input MFMAs at 16x the rate of the fp32-input MFMA.  Every fp32 operand x is split into a
 // short sum of 16-bit terms whose pairwise products are exact in fp32 (the MFMA accumulates in fp32), and a product
 // a*b is formed from the term pairs that matter.  KIND selects the split:
-//   KIND 2 (default, fp32 inputs)  x * 2^s = hi + lo, two fp16 terms (hi = fp16(x'), lo = fp16(x' - hi), the subtraction
+//   KIND 2 (fp32 inputs)           x * 2^s = hi + lo, two fp16 terms (hi = fp16(x'), lo = fp16(x' - hi), the subtraction
 //          is exact: 22 significant bits); products lo*hi, hi*lo, hi*hi (the dropped lo*lo is 2^-22 relative).  fp16 has
 //          a 5-bit exponent, so operands are pre-scaled by powers of two (exact, undone exactly in the epilogues):
 //          theta^T and score^T per column to a column maximum in [2^13, 2^14), theta for the distance GEMM by one factor
 //          for the whole matrix, and P = exp2(c D + 14) in (0, 2^14].  An entry far below its column's maximum keeps
 //          an ABSOLUTE error of 2^-25 of the scaled unit, i.e. 2^-38 of the column maximum -- the same norm-wise
 //          guarantee an fp32 GEMM gives.
-//   KIND 3 (STEIN_SPLIT_KIND=b3)   x = hi + mid + lo, three bf16 terms (24 significant bits, no scaling needed); the six
-//          products >= 2^-16: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  Twice the matrix-core time of KIND 2.
+//          (A three-term bf16 split, six products and no scaling, was measured in round 1: same accuracy, twice the
+//          matrix-core time; it is no longer built.)
 //   KIND 1 (bf16 inputs)           the value itself; one product.
 //
 //   k_colmax, k_make_scales   column maxima -> power-of-two scales (KIND 2; all ones otherwise)
@@ -23,7 +23,7 @@
 // Both GEMMs are "row x row" products (C[i][c] = sum_k A[i][k] B[c][k]) with k contiguous for both operands.
 //
 // Operand tile = 128 rows x 32 k of one plane = [128][32] x 16 bit = 8 KB; a tile has three plane slots (24 KB, KIND of
-// them used) and tiles are stored tile-major:  tile(rb, kt) at ((rb * ntk + kt) * 3 + plane) * 4096 elements.
+// them used; the third is a leftover of the three-term split) and tiles are stored tile-major:  tile(rb, kt) at ((rb * ntk + kt) * 3 + plane) * 4096 elements.
 // One wave-wide 16-byte-per-lane load therefore covers 1 KB of consecutive memory (row-major planes made every
 // 64-byte row piece its own cache-line visit: the producers spent 2900 cycles per k tile issuing loads).
 //   T3   rows = particles, k = parameters   (distance operands; rows of a tile may straddle two row blocks when a
@@ -124,21 +124,10 @@ __device__ __forceinline__ float f16_resid_hi(u32 h, float x) {
   return r;
 }
 
-// two fp32 values -> three packed bf16 pairs (x in the low half)
-__device__ __forceinline__ void split3_pair(float x, float y, u32& hi, u32& mid, u32& lo) {
-  hi = cvt_pk_bf16(x, y);
-  const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);   // exact
-  mid = cvt_pk_bf16(rx, ry);
-  const float sx = rx - __uint_as_float(mid << 16), sy = ry - __uint_as_float(mid & 0xffff0000u);  // exact
-  lo = cvt_pk_bf16(sx, sy);
-}
-
 // two fp32 values -> KIND packed 16-bit pairs w[0..KIND) (x in the low half), most significant term first
 template <int KIND>
 __device__ __forceinline__ void split_pair(float x, float y, u32 (&w)[3]) {
-  if (KIND == 3) {
-    split3_pair(x, y, w[0], w[1], w[2]);
-  } else if (KIND == 2) {
+  if (KIND == 2) {
     w[0] = cvt_pk_f16(x, y);
     w[1] = cvt_pk_f16(f16_resid_lo(w[0], x), f16_resid_hi(w[0], y));
   } else {
@@ -338,7 +327,7 @@ __device__ __forceinline__ void x3_store_swz(unsigned char* oper, int t, const u
 }
 
 // The products of one fragment pair, smallest first (plane 0 = most significant term).  NP is the split KIND = the
-// number of planes: 3 -> six bf16 products, 2 -> three fp16 products, 1 -> one bf16 product.  Fragments are held
+// number of planes: 2 -> three fp16 products, 1 -> one bf16 product.  Fragments are held
 // as 32-bit vectors and bit-cast at the MFMA (loop-carried 16-bit vectors get scalarised by the compiler).
 #define X3_BF(v) __builtin_bit_cast(bf16x8, v)
 #define X3_HF(v) __builtin_bit_cast(f16x8, v)
@@ -348,13 +337,6 @@ __device__ __forceinline__ f32x16 x3_products(const u32x4 (&a)[3], const u32x4 (
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(X3_HF(a[1]), X3_HF(b[0]), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(X3_HF(a[0]), X3_HF(b[1]), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(X3_HF(a[0]), X3_HF(b[0]), c, 0, 0, 0);
-  }
-  if (NP == 3) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[2]), X3_BF(b[0]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[2]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[1]), X3_BF(b[1]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[1]), X3_BF(b[0]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[1]), c, 0, 0, 0);
   }
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[0]), c, 0, 0, 0);
 }
@@ -366,13 +348,6 @@ __device__ __forceinline__ f32x4 x3_products16(const u32x4 (&a)[3], const u32x4 
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[1]), X3_HF(b[0]), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[0]), X3_HF(b[1]), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[0]), X3_HF(b[0]), c, 0, 0, 0);
-  }
-  if (NP == 3) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[2]), X3_BF(b[0]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[2]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[1]), X3_BF(b[1]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[1]), X3_BF(b[0]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[1]), c, 0, 0, 0);
   }
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[0]), c, 0, 0, 0);
 }
@@ -477,7 +452,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
 //                            B fragments (V) by one coalesced 1 KB global load each, issued one k tile ahead right
 //                            after the registers' last use; 48 MFMAs per k tile and wave
 //   Every SIMD holds one producer and two consumers.  V never touches LDS and is fetched exactly once per workgroup
-//   (no two waves share a B fragment).  One barrier per pipeline stage (four k tiles; two for the three-plane kind)
+//   (no two waves share a B fragment).  One barrier per pipeline stage (four k tiles)
 //   hands the P stages over.
 //   Column space: the 128-column blocks of [G | theta] (each matrix padded to dc = roundup(d, 128)) are paired up,
 //   block cb covers pair (2cb, 2cb+1); consumer wave cw takes half cw >> 2, 32-column block cw & 3.
@@ -485,7 +460,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
 constexpr int FS_THREADS = 768;
 // k tiles per pipeline stage (even: tile parity picks the register set) and the LDS of one k tile (NP planes, packed)
 template <int NP> struct FsGeom {
-  static constexpr int KT = NP == 3 ? 2 : 4;          // 2 stages x KT x NP x 8 KB: 128 KB (NP 2), 96 KB (NP 3), 64 KB (NP 1)
+  static constexpr int KT = 4;                        // 2 stages x KT x NP x 8 KB: 128 KB (NP 2), 64 KB (NP 1)
   static constexpr int KTB = NP * XPLANE;
   static constexpr int STAGE = KT * KTB;
 };
@@ -520,7 +495,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     // PD register sets (tile index mod PD picks the set): the loads of tile t + PD are issued as soon as tile t has been
     // turned into LDS data.  D streams from HBM (never re-used), so the loads need several tiles of lead
-    constexpr int PD = FS_KT;   // 4 (2 for the three-plane kind); FS_KT % PD == 0 keeps the set index static
+    constexpr int PD = FS_KT;   // 4; FS_KT % PD == 0 keeps the set index static
     float4 rd[PD][4];
     u32 doff[4];
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
@@ -725,15 +700,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 // ================================================================================================
 // host side
 // ================================================================================================
-// split KIND of a call: bf16 inputs -> 1; fp32 inputs -> 2 (two fp16 terms), or 3 (three bf16 terms) when the
-// environment says STEIN_SPLIT_KIND=b3 (kept for accuracy / speed comparisons; read once per process)
-static int split_kind(int dtype) {
-  static const int f32_kind = [] {
-    const char* e = getenv("STEIN_SPLIT_KIND");
-    return (e && e[0] == 'b' && e[1] == '3') ? 3 : 2;
-  }();
-  return dtype == STEIN_BF16 ? 1 : f32_kind;
-}
+// split KIND of a call: bf16 inputs -> 1 (the values themselves); fp32 inputs -> 2 (two fp16 terms of the scaled value)
+static int split_kind(int dtype) { return dtype == STEIN_BF16 ? 1 : 2; }
 int stein_x3_kind(int dtype) { return split_kind(dtype); }
 
 template <typename TIN, int KIND>
@@ -781,8 +749,7 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
     LAUNCH_CHECK("k_make_scales");
   }
   if (kind == 1) launch_split<u16, 1>(stream, (const u16*)theta_all, (const u16*)score_all, n, d, L, T3, Tt3, Gt3, sc);
-  else if (kind == 2) launch_split<float, 2>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
-  else launch_split<float, 3>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
+  else launch_split<float, 2>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
   LAUNCH_CHECK("k_split");
   return STEIN_OK;
 }
@@ -808,8 +775,7 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
 #define X3_DIST(SYM, NP) launch_distance_x3<SYM, NP>(nblk, stream, T3, ntk, r_all, dist_out, (int)n, (int)row0, (int)n_local, (long)ld_dist, tiles_m, tiles_n, hist0, two_s, spec, spec_buf)
   switch (split_kind(dtype)) {
     case 1: if (symmetric) X3_DIST(true, 1); else X3_DIST(false, 1); break;
-    case 2: if (symmetric) X3_DIST(true, 2); else X3_DIST(false, 2); break;
-    default: if (symmetric) X3_DIST(true, 3); else X3_DIST(false, 3); break;
+    default: if (symmetric) X3_DIST(true, 2); else X3_DIST(false, 2); break;
   }
 #undef X3_DIST
   LAUNCH_CHECK("k_distance_x3");
@@ -826,8 +792,7 @@ int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* pl
 #define X3_PHI(NP) hipLaunchKernelGGL(k_phi_x3fs<NP>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3, (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m, (int)L.cblocks, (int)L.split, (int)L.jchunk, sc, (int)L.x3_dc)
   switch (split_kind(dtype)) {
     case 1: X3_PHI(1); break;
-    case 2: X3_PHI(2); break;
-    default: X3_PHI(3); break;
+    default: X3_PHI(2); break;
   }
 #undef X3_PHI
   LAUNCH_CHECK("k_phi_x3fs");

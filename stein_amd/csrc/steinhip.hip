@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void k_resolve(const u64* __restrict__ hist, in
 // fused-call prologue: k_sel_init + the window set-up + zeroing of the histograms and of the "below" slots
 // (gt of gn threads share the zeroing; thread 0 sets the states up)
 __device__ __forceinline__ void median_init_body(int gt, int gn, SelState* st, SpecState* sp, u64 total,
-                                                 u64* __restrict__ hist, u64* __restrict__ slots) {
+                                                 u64* __restrict__ hist, u64* __restrict__ slots, int allow_window = 1) {
   for (int i = gt; i < STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS; i += gn) hist[i] = 0ull;
   for (int i = gt; i < (int)SPEC_SLOTS * 8; i += gn) slots[i] = 0ull;
   if (gt) return;
@@ -399,7 +399,7 @@ __device__ __forceinline__ void median_init_body(int gt, int gn, SelState* st, S
   }
   // a window is granted only among the keys of positive finite floats, [0x80000000, 0xff000000): the distance epilogue
   // tests raw bit patterns (a median <= 0 means coincident particles: h2 = 0, nothing to speed up)
-  if ((sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) && sp->halfwidth <= SPEC_HW_MAX &&
+  if (allow_window && (sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) && sp->halfwidth <= SPEC_HW_MAX &&
       sp->center >= 0x80000000u + sp->halfwidth && sp->center < 0xff000000u - sp->halfwidth) {
     sp->lo_key = sp->center - sp->halfwidth;
     sp->width = 2u * sp->halfwidth;
@@ -425,12 +425,12 @@ template <typename TIN>
 __global__ __launch_bounds__(256) void k_prologue(const TIN* __restrict__ T, int n, int d, float* __restrict__ r,
                                                   int row_blocks, SelState* st, SpecState* sp, FuseState* fs, u64 total,
                                                   u64* __restrict__ hist, u64* __restrict__ slots,
-                                                  u32* __restrict__ cmax, int ncmax) {
+                                                  u32* __restrict__ cmax, int ncmax, int allow_window) {
   if ((int)blockIdx.x >= row_blocks) {
     const int gt = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x, gn = PRO_INIT_BLOCKS * 256;
     for (int i = gt; i < ncmax; i += gn) cmax[i] = 0u;
     if (gt < 16) reinterpret_cast<u32*>(fs)[gt] = 0u;
-    median_init_body(gt, gn, st, sp, total, hist, slots);
+    median_init_body(gt, gn, st, sp, total, hist, slots, allow_window);
     return;
   }
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -720,8 +720,12 @@ __device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* s
       if (sp->hit && sp->count > SPEC_CAP / 2 && hw > sp->halfwidth / 2u) hw = sp->halfwidth / 2u + 1u;   // keep the buffer small
     }
     sp->magic = SPEC_MAGIC2;
+    sp->n_steps += 1u;
+    sp->n_hits += sp->hit ? 1u : 0u;
   } else {
     sp->magic = SPEC_MAGIC1;
+    sp->n_steps = 1u;
+    sp->n_hits = 0u;
   }
   sp->last_key = key;
   sp->center = next;
@@ -982,8 +986,8 @@ __device__ __forceinline__ C adagrad_elem(C p, C h, int first, C a, C na, C ep, 
   return p / (ep + sqrt(hs)) * l;
 }
 
-template <typename S>
-__global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, const float* __restrict__ phi,
+template <typename S, typename P>
+__global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, const P* __restrict__ phi,
                                                        S* __restrict__ hist, long count, const double* sq,
                                                        double host_scale, double thr, double lr, double alpha,
                                                        double eps, int first, S* __restrict__ step_out, int vec) {
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, co
   typedef typename std::conditional<sizeof(S) == 4, float, double>::type C;
   const C scale = (C)clip_scale_of(sq, host_scale, thr);
   const C a = (C)alpha, na = (C)(1.0 - alpha), ep = (C)eps, l = (C)lr;
-  if (sizeof(S) == 4 && vec) {   // host: count % 4 == 0, theta present, every pointer 16-byte aligned, no step_out
+  if (sizeof(S) == 4 && sizeof(P) == 4 && vec) {   // host: count % 4 == 0, theta present, every pointer 16-byte aligned, no step_out
     float4* th4 = reinterpret_cast<float4*>(theta);
     float4* hi4 = reinterpret_cast<float4*>(hist);
     const float4* ph4 = reinterpret_cast<const float4*>(phi);
@@ -1025,8 +1029,8 @@ __global__ __launch_bounds__(256) void k_apply_adagrad(S* __restrict__ theta, co
   }
 }
 
-template <typename S>
-__global__ __launch_bounds__(256) void k_apply_adam(S* __restrict__ theta, const float* __restrict__ phi,
+template <typename S, typename P>
+__global__ __launch_bounds__(256) void k_apply_adam(S* __restrict__ theta, const P* __restrict__ phi,
                                                     S* __restrict__ mu, S* __restrict__ nu, long count,
                                                     const double* sq, double host_scale, double thr, double lr,
                                                     double b1, double b2, double eps, int first, double corr1,
@@ -1066,7 +1070,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
-  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -1087,10 +1091,6 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
     const double rounds = (double)(base * s) / resident;
     const double eff = rounds / ceil(rounds) - 0.004 * (double)(s - 1);
     if (eff > best + 1e-9) { best = eff; split = s; }
-  }
-  if (const char* e = getenv("STEIN_SPLIT")) {  // experiments only
-    const long v = atol(e);
-    if (v >= 1 && v <= max_split) split = v;
   }
   const int64_t tiles_per = (jt + split - 1) / split;
   L->jchunk = tiles_per * BK;
@@ -1114,7 +1114,10 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
     const int64_t small = (d + 31) / 32;
     put(STEIN_WS_SQPART, (size_t)(sqb > small ? sqb : small) * 8);
   }
-  put(STEIN_WS_SPEC, ((size_t)SPEC_CAP + SPEC_SLOTS * 8 + SPEC_TABLE) * 8);   // slots | entries | rank-summed table
+  // slots | entries | rank-summed table.  Empty when the fused call will take the one-kernel path (stein_small.hip never
+  // touches it): the reference's own example sizes then carry a few hundred KB of workspace instead of 16.5 MB
+  const bool small_path = !(flags & STEIN_FLAG_TILED) && n_local == n && stein_small_ok(n, d, dtype);
+  put(STEIN_WS_SPEC, small_path ? 0 : ((size_t)SPEC_CAP + SPEC_SLOTS * 8 + SPEC_TABLE) * 8);
   // split operand planes: always LAST so the offsets above do not depend on the flag
   L->x3_rows = (int64_t)align_up((size_t)n, 128) + 128;   // a rank's last row tile may start past roundup(n, 128) - 128
   L->x3_dk = (int64_t)align_up((size_t)d, 32);
@@ -1446,10 +1449,10 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage timing of the fused call (profiling aid; process-global, not thread-safe)
+// stage timing of the fused call (profiling aid; per calling thread, like the last-error string)
 // ------------------------------------------------------------------------------------------------
-static std::vector<hipEvent_t> g_tevents;   // (STEIN_T_NSTAGES + 1) events per reserved call
-static int g_tcalls_reserved = 0, g_tcalls_used = 0;
+static thread_local std::vector<hipEvent_t> g_tevents;   // (STEIN_T_NSTAGES + 1) events per reserved call
+static thread_local int g_tcalls_reserved = 0, g_tcalls_used = 0;
 
 extern "C" int stein_timing_reserve(int calls) {
   if (calls < 0) return fail(STEIN_E_BADARG, "calls < 0");
@@ -1535,13 +1538,15 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
       ncmax = (int)(2 * L.x3_dc);
     }
     const int row_blocks = (int)((n + 3) / 4);
+    const int allow_window = (flags & STEIN_FLAG_NO_WINDOW) ? 0 : 1;
     const dim3 grid((unsigned)(row_blocks + PRO_INIT_BLOCKS));
     if (dtype == STEIN_BF16)
       hipLaunchKernelGGL(k_prologue<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)theta_all, (int)n,
-                         (int)d, r, row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax);
+                         (int)d, r, row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax,
+                         allow_window);
     else
       hipLaunchKernelGGL(k_prologue<float>, grid, dim3(256), 0, s, (const float*)theta_all, (int)n, (int)d, r,
-                         row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax);
+                         row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax, allow_window);
     LAUNCH_CHECK("k_prologue");
   }
   if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax)))
@@ -1579,55 +1584,67 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   return STEIN_OK;
 }
 
-template <typename S>
-static int apply_adagrad_t(void* theta, const float* phi, void* hist, int64_t count, const double* sq, double hs,
+template <typename S, typename P>
+static int apply_adagrad_t(void* theta, const void* phi, void* hist, int64_t count, const double* sq, double hs,
                            double thr, double lr, double alpha, double eps, int first, void* step_out, void* stream) {
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
-  const int vec = sizeof(S) == 4 && count % 4 == 0 && theta && !step_out && al16(theta) && al16(phi) && al16(hist);
-  hipLaunchKernelGGL(k_apply_adagrad<S>, dim3(grid_for(vec ? count / 4 : count, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     (S*)theta, phi, (S*)hist, (long)count, sq, hs, thr, lr, alpha, eps, first, (S*)step_out, vec);
+  const int vec = sizeof(S) == 4 && sizeof(P) == 4 && count % 4 == 0 && theta && !step_out && al16(theta) && al16(phi) && al16(hist);
+  hipLaunchKernelGGL((k_apply_adagrad<S, P>), dim3(grid_for(vec ? count / 4 : count, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (S*)theta, (const P*)phi, (S*)hist, (long)count, sq, hs, thr, lr, alpha, eps, first, (S*)step_out, vec);
   LAUNCH_CHECK("k_apply_adagrad");
   return STEIN_OK;
 }
 
-extern "C" int stein_apply_adagrad(void* theta, const float* phi, void* hist, int64_t count, int state_dtype,
+// phi_dtype STEIN_F64 needs fp64 state: the reference's pure-fp64 `gd.update(phi)` (no rounding of phi to fp32)
+static int check_apply_dtypes(int state_dtype, int phi_dtype) {
+  if (state_dtype != STEIN_F32 && state_dtype != STEIN_F64) return fail(STEIN_E_UNSUPPORTED, "state dtype %d", state_dtype);
+  if (phi_dtype != STEIN_F32 && phi_dtype != STEIN_F64) return fail(STEIN_E_UNSUPPORTED, "phi dtype %d", phi_dtype);
+  if (phi_dtype == STEIN_F64 && state_dtype != STEIN_F64) return fail(STEIN_E_UNSUPPORTED, "fp64 phi needs fp64 optimizer state");
+  return STEIN_OK;
+}
+
+extern "C" int stein_apply_adagrad(void* theta, const void* phi, int phi_dtype, void* hist, int64_t count, int state_dtype,
                                    const double* sqnorm_dev, double clip_scale_host, double clip_threshold, double lr,
                                    double alpha, double eps, int first_step, void* step_out, void* stream) {
   if (!phi || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (count < 1) return fail(STEIN_E_SHAPE, "count < 1");
+  if (int rc = check_apply_dtypes(state_dtype, phi_dtype)) return rc;
   if (state_dtype == STEIN_F32)
-    return apply_adagrad_t<float>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha, eps,
-                                  first_step, step_out, stream);
-  if (state_dtype == STEIN_F64)
-    return apply_adagrad_t<double>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha,
-                                   eps, first_step, step_out, stream);
-  return fail(STEIN_E_UNSUPPORTED, "state dtype %d", state_dtype);
+    return apply_adagrad_t<float, float>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha, eps,
+                                         first_step, step_out, stream);
+  if (phi_dtype == STEIN_F32)
+    return apply_adagrad_t<double, float>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha,
+                                          eps, first_step, step_out, stream);
+  return apply_adagrad_t<double, double>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha,
+                                         eps, first_step, step_out, stream);
 }
 
-template <typename S>
-static int apply_adam_t(void* theta, const float* phi, void* mu, void* nu, int64_t count, const double* sq, double hs,
+template <typename S, typename P>
+static int apply_adam_t(void* theta, const void* phi, void* mu, void* nu, int64_t count, const double* sq, double hs,
                         double thr, double lr, double b1, double b2, double eps, int64_t t, void* step_out,
                         void* stream) {
   const double corr1 = 1.0 - pow(b1, (double)t), corr2 = 1.0 - pow(b2, (double)t);
-  hipLaunchKernelGGL(k_apply_adam<S>, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, (S*)theta, phi,
-                     (S*)mu, (S*)nu, (long)count, sq, hs, thr, lr, b1, b2, eps, t == 1 ? 1 : 0, corr1, corr2,
+  hipLaunchKernelGGL((k_apply_adam<S, P>), dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, (S*)theta,
+                     (const P*)phi, (S*)mu, (S*)nu, (long)count, sq, hs, thr, lr, b1, b2, eps, t == 1 ? 1 : 0, corr1, corr2,
                      (S*)step_out);
   LAUNCH_CHECK("k_apply_adam");
   return STEIN_OK;
 }
 
-extern "C" int stein_apply_adam(void* theta, const float* phi, void* mu, void* nu, int64_t count, int state_dtype,
-                                const double* sqnorm_dev, double clip_scale_host, double clip_threshold, double lr,
-                                double beta1, double beta2, double eps, int64_t t, void* step_out, void* stream) {
+extern "C" int stein_apply_adam(void* theta, const void* phi, int phi_dtype, void* mu, void* nu, int64_t count,
+                                int state_dtype, const double* sqnorm_dev, double clip_scale_host, double clip_threshold,
+                                double lr, double beta1, double beta2, double eps, int64_t t, void* step_out, void* stream) {
   if (!phi || !mu || !nu) return fail(STEIN_E_BADARG, "NULL pointer");
   if (count < 1 || t < 1) return fail(STEIN_E_SHAPE, "count < 1 or t < 1");
+  if (int rc = check_apply_dtypes(state_dtype, phi_dtype)) return rc;
   if (state_dtype == STEIN_F32)
-    return apply_adam_t<float>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
-                               beta2, eps, t, step_out, stream);
-  if (state_dtype == STEIN_F64)
-    return apply_adam_t<double>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
-                                beta2, eps, t, step_out, stream);
-  return fail(STEIN_E_UNSUPPORTED, "state dtype %d", state_dtype);
+    return apply_adam_t<float, float>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
+                                      beta2, eps, t, step_out, stream);
+  if (phi_dtype == STEIN_F32)
+    return apply_adam_t<double, float>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
+                                       beta2, eps, t, step_out, stream);
+  return apply_adam_t<double, double>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
+                                      beta2, eps, t, step_out, stream);
 }
 
 extern "C" int stein_cast_f64_to_f32(const double* src, float* dst, int64_t count, void* stream) {

@@ -67,57 +67,57 @@ class HipStages:
         return _lib.workspace_layout(n_local, n, d, _lib.F32, flags)
 
     def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws, flags=0):
-        _lib.call("stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _dt(T), _ptr(phi), _ptr(h2), _ptr(sqnorm),
+        _lib.call_on(T.device, "stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _dt(T), _ptr(phi), _ptr(h2), _ptr(sqnorm),
                   _ptr(K), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
     def x3_prepare(self, T, G, n, d, planes):
         """T or G may be None: only the other matrix's scales and planes are rebuilt."""
         ref = T if T is not None else G
-        _lib.call("stein_x3_prepare", _ptr(T), _ptr(G), n, d, _dt(ref), _ptr(planes), planes.numel(), _stream(ref))
+        _lib.call_on(ref.device, "stein_x3_prepare", _ptr(T), _ptr(G), n, d, _dt(ref), _ptr(planes), planes.numel(), _stream(ref))
 
     def rownorms(self, T, n, d, r):
-        _lib.call("stein_rownorms", _ptr(T), n, d, _dt(T), _ptr(r), _stream(T))
+        _lib.call_on(T.device, "stein_rownorms", _ptr(T), n, d, _dt(T), _ptr(r), _stream(T))
 
     def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None):
-        _lib.call("stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
+        _lib.call_on(T.device, "stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
                   _ptr(planes), _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
 
     # -- speculative median window across ranks (include/steinhip.h) --
     def spec_begin(self, hist, sel, spec, total):
-        _lib.call("stein_spec_begin", _ptr(hist), _ptr(sel), _ptr(spec), total, _stream(hist))
+        _lib.call_on(hist.device, "stein_spec_begin", _ptr(hist), _ptr(sel), _ptr(spec), total, _stream(hist))
 
     def distance_block_spec(self, T, r, n, d, row0, n_local, D, ld, hist0, sel, spec, planes=None):
-        _lib.call("stein_distance_block_spec", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
+        _lib.call_on(T.device, "stein_distance_block_spec", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
                   _ptr(planes), 0, _ptr(sel), _ptr(spec), _stream(T))
 
     def spec_tally(self, sel, spec):
-        _lib.call("stein_spec_tally", _ptr(sel), _ptr(spec), _stream(sel))
+        _lib.call_on(sel.device, "stein_spec_tally", _ptr(sel), _ptr(spec), _stream(sel))
 
     def spec_pick(self, sel, spec, n, h2, median):
-        _lib.call("stein_spec_pick", _ptr(sel), _ptr(spec), n, _ptr(h2), _ptr(median), _stream(sel))
+        _lib.call_on(sel.device, "stein_spec_pick", _ptr(sel), _ptr(spec), n, _ptr(h2), _ptr(median), _stream(sel))
 
     def spec_update(self, sel):
-        _lib.call("stein_spec_update", _ptr(sel), _stream(sel))
+        _lib.call_on(sel.device, "stein_spec_update", _ptr(sel), _stream(sel))
 
     def median_begin(self, hist, sel, total):
-        _lib.call("stein_median_begin", _ptr(hist), _ptr(sel), total, _stream(hist))
+        _lib.call_on(hist.device, "stein_median_begin", _ptr(hist), _ptr(sel), total, _stream(hist))
 
     def median_hist_pass(self, D, ld, n_local, n, level, sel, hist, symmetric=False):
-        _lib.call("stein_median_hist_pass", _ptr(D), ld, n_local, n, level, _ptr(sel), _ptr(hist),
+        _lib.call_on(D.device, "stein_median_hist_pass", _ptr(D), ld, n_local, n, level, _ptr(sel), _ptr(hist),
                   _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(D))
 
     def median_resolve(self, hist, level, n, sel, h2, median):
-        _lib.call("stein_median_resolve", _ptr(hist), level, n, _ptr(sel), _ptr(h2), _ptr(median), _stream(hist))
+        _lib.call_on(hist.device, "stein_median_resolve", _ptr(hist), level, n, _ptr(sel), _ptr(h2), _ptr(median), _stream(hist))
 
     def kernel_matrix(self, D, ld, n_local, n, h2, K):
-        _lib.call("stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
+        _lib.call_on(D.device, "stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
 
     def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None):
-        _lib.call("stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _dt(T), _ptr(h2),
+        _lib.call_on(D.device, "stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _dt(T), _ptr(h2),
                   _ptr(planes), _ptr(ws), ws.numel(), _stream(D))
 
     def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, flags=0):
-        _lib.call("stein_contract_finish", _ptr(T), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi),
+        _lib.call_on(T.device, "stein_contract_finish", _ptr(T), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi),
                   _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
     def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
@@ -137,7 +137,8 @@ class SvgdEngine:
               (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
     """
 
-    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True):
+    def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True,
+                 window=True, force_collectives=False):
         self.n, self.d = int(n), int(d)
         # dtype of the theta / score tensors handed to compute_phi: float32, or bfloat16 (BASELINE config 2: the
         # values are used as they are, K is rounded to bf16, one bf16 MFMA per product, fp32 accumulation)
@@ -151,7 +152,10 @@ class SvgdEngine:
             x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
         self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
         # small=False: the fused call never takes the one-kernel path for n <= 160 (tests of the tiled kernels)
-        self.flags = (_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED)
+        # window=False: the fused call never uses the speculative median window (every step pays the radix-select passes;
+        # same results -- bench.py times the miss path this way)
+        self.flags = ((_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED) |
+                      (0 if window else _lib.FLAG_NO_WINDOW))
         # several ranks: use the speculative median window (one 512 KB all-reduce and a hit-flag read-back per step
         # instead of two passes over the local distance block) when the block is large enough for that to pay
         # (>= 2^27 entries: the two passes then cost more than the table all-reduce plus the read-back stall);
@@ -166,6 +170,10 @@ class SvgdEngine:
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
+        # sharded: run the multi-rank protocol (gathers, histogram / table / scalar all-reduces between the staged calls).
+        # force_collectives runs it on a one-rank group as well -- how the tests drive every collective through RCCL on
+        # a single card.
+        self.sharded = self.world > 1 or (group is not None and force_collectives)
         if self.n < 2:
             raise ValueError("n_particles = %d: the median-heuristic bandwidth divides by ln(n); need n >= 2" % self.n)
         if self.n % self.world:
@@ -178,14 +186,18 @@ class SvgdEngine:
         self.ld_dist, self.split = extra[_lib.WSX_LD_DIST], extra[_lib.WSX_SPLIT]
         dev = self.device
         self.ws = torch.empty(total, dtype=torch.uint8, device=dev)
+        # the SELECT section carries the median predictor from call to call and is trusted once its magic word matches:
+        # start it clean, so that which select path runs never depends on what the allocator's block held before
+        o = offs[_lib.WS_SELECT]
+        self.ws[o:o + _lib.SELECT_BYTES].zero_()
         self.phi = torch.empty(self.n_local, self.d, dtype=torch.float32, device=dev)
         self.h2 = torch.zeros(1, dtype=torch.float32, device=dev)
         self.median = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
-        if self.world > 1 and hasattr(self.stages, "spec_begin"):
+        if self.sharded and hasattr(self.stages, "spec_begin"):
             env = os.environ.get("STEIN_DIST_WINDOW", "")
             self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 27))
-        if self.world > 1:
+        if self.sharded:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
 
@@ -219,6 +231,12 @@ class SvgdEngine:
         """radix-select state (64 bytes) followed by the speculative-window state (64 bytes)"""
         return self._section(_lib.WS_SELECT, 128, torch.uint8)
 
+    def window_stats(self):
+        """(medians recorded since the predictor started, how many of them the speculative window delivered) --
+        counted on the device by the library; reading them synchronises with the stream."""
+        w = self.select_state[_lib.SPEC_NSTEPS_OFFSET:_lib.SPEC_NHITS_OFFSET + 4].view(torch.int32).cpu()
+        return int(w[0]), int(w[1])
+
     @property
     def spec_section(self):
         o = self._offs[_lib.WS_SPEC]
@@ -243,11 +261,11 @@ class SvgdEngine:
         """Levels first_level..2 of the radix select: local histogram pass (level 0 normally comes from the distance
         epilogue), all-reduce over the ranks, resolve."""
         st, n, nl, D, ld, hist, sel = self.stages, self.n, self.n_local, self.dist, self.ld_dist, self.hist, self.select_state
-        sym = self.world == 1
+        sym = not self.sharded
         for level in range(first_level, _lib.HIST_LEVELS):
             if level > 0 or need_level0_pass:
                 st.median_hist_pass(D, ld, nl, n, level, sel, hist, symmetric=sym)
-            if self.world > 1:
+            if self.sharded:
                 import torch.distributed as dist
                 dist.all_reduce(hist[level], op=dist.ReduceOp.SUM, group=self.group)
             st.median_resolve(hist, level, n, sel, self.h2, self.median)
@@ -292,7 +310,7 @@ class SvgdEngine:
             if tuple(t.shape) != (nl, d) or t.dtype != self.dtype or not t.is_contiguous():
                 raise ValueError("%s must be a contiguous %s [%d, %d] tensor, got %s %s" %
                                  (name, self.dtype, nl, d, tuple(t.shape), t.dtype))
-        if self.world == 1 and mark is None:
+        if not self.sharded and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
                         self.flags | (_lib.FLAG_TIMING if timing else 0))
             return self.phi
@@ -301,7 +319,7 @@ class SvgdEngine:
                 return None
 
         gather_g = None
-        if self.world > 1:
+        if self.sharded:
             import torch.distributed as dist
             mark("gather")
             # theta first (collectives of one group run in issue order); the score rows are not needed before the
@@ -319,7 +337,7 @@ class SvgdEngine:
             st.x3_prepare(T_all, None if gather_g is not None else G_all, n, d, planes)
         # the distance pass fills the level-0 histogram from its accumulators; a single rank holds the whole
         # symmetric matrix and only computes / counts its upper triangle
-        sym = self.world == 1
+        sym = not self.sharded
         if self.dist_window:
             self._median_with_window(T_all, mark)
         else:
@@ -339,7 +357,7 @@ class SvgdEngine:
         st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws, planes)
         mark("finish")
         st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws, self.flags)
-        if self.world > 1:
+        if self.sharded:
             dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
         mark("end")
         return self.phi

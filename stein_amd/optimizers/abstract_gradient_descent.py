@@ -41,17 +41,35 @@ class AbstractGradientDescent:
 
     @staticmethod
     def _as_device_phi(phi, device=None):
-        """-> (float32 contiguous device tensor, state dtype, was_numpy)."""
+        """-> (contiguous device tensor, state dtype, was_numpy).
+
+        float64 input (every NumPy array, float64 tensors) stays float64 on the device and gets float64 state:
+        the reference's ``gd.update(phi)`` is pure fp64 NumPy (adagrad_gradient_descent.py:37-44,
+        adam_gradient_descent.py:44-58), so phi must not be rounded to fp32 on the way in.  Anything else is
+        float32 with float32 state."""
         if isinstance(phi, torch.Tensor):
-            state_dtype = torch.float64 if phi.dtype == torch.float64 else torch.float32
+            dt = torch.float64 if phi.dtype == torch.float64 else torch.float32
             if not phi.is_cuda:
                 phi = phi.to(device or "cuda")
-            return phi.to(torch.float32).contiguous(), state_dtype, False
-        arr = np.asarray(phi)
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device or "cuda")
-        return t, torch.float64, True   # NumPy callers get the reference's fp64 state and step
+            return phi.to(dt).contiguous(), dt, False
+        arr = np.ascontiguousarray(np.asarray(phi), dtype=np.float64)
+        return torch.from_numpy(arr).to(device or "cuda"), torch.float64, True
 
-    def _launch(self, theta, phi32, state_dtype, sqnorm_dev, clip_scale, step_out):
+    def _state_for(self, name, shape, dtype, device, first):
+        """The state tensor `name`, created on the first update.  A later call in the other precision (``update`` on a
+        NumPy array after ``apply_`` on float32 particles, or the reverse) converts the state instead of failing; a
+        change of shape is an error."""
+        cur = getattr(self, name)
+        if cur is None or cur.shape != shape:
+            if not first:
+                raise ValueError("phi shape changed between updates")
+            cur = self._new_state(shape, dtype, device)
+        elif cur.dtype != dtype:
+            cur = cur.to(dtype)
+        setattr(self, name, cur)
+        return cur
+
+    def _launch(self, theta, phi, state_dtype, sqnorm_dev, clip_scale, step_out):
         raise NotImplementedError()
 
     def _state_tensors(self):
@@ -63,9 +81,9 @@ class AbstractGradientDescent:
 
         Equivalent of ``gd.update(phi)`` in the reference: no clipping here, no theta.
         """
-        phi32, state_dtype, was_numpy = self._as_device_phi(phi, self._device)
-        step = torch.empty(phi32.shape, dtype=state_dtype, device=phi32.device)
-        self._launch(None, phi32, state_dtype, None, 1.0, step)
+        phid, state_dtype, was_numpy = self._as_device_phi(phi, self._device)
+        step = torch.empty(phid.shape, dtype=state_dtype, device=phid.device)
+        self._launch(None, phid, state_dtype, None, 1.0, step)
         if was_numpy:
             return step.cpu().numpy()
         return step if phi.dtype == state_dtype else step.to(phi.dtype)

@@ -29,14 +29,11 @@ class AdagradGradientDescent(AbstractGradientDescent):
     def _state_tensors(self):
         return {"hist": self._hist}
 
-    def _launch(self, theta, phi32, state_dtype, sqnorm_dev, clip_scale, step_out):
+    def _launch(self, theta, phi, state_dtype, sqnorm_dev, clip_scale, step_out):
         first = self.n_iters == 0
-        if self._hist is None or self._hist.shape != phi32.shape or self._hist.dtype != state_dtype:
-            if not first:
-                raise ValueError("phi shape/dtype changed between updates")
-            self._hist = self._new_state(phi32.shape, state_dtype, phi32.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(phi32.device).cuda_stream)
-        _lib.call("stein_apply_adagrad", _vp(theta), _vp(phi32), _vp(self._hist), phi32.numel(), _code(state_dtype),
-                  _vp(sqnorm_dev), float(clip_scale), CLIP_THRESHOLD, float(self.learning_rate), float(self.alpha),
-                  EPS, 1 if first else 0, _vp(step_out), stream)
+        hist = self._state_for("_hist", phi.shape, state_dtype, phi.device, first)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(phi.device).cuda_stream)
+        _lib.call_on(phi.device, "stein_apply_adagrad", _vp(theta), _vp(phi), _code(phi.dtype), _vp(hist), phi.numel(),
+                     _code(state_dtype), _vp(sqnorm_dev), float(clip_scale), CLIP_THRESHOLD, float(self.learning_rate),
+                     float(self.alpha), EPS, 1 if first else 0, _vp(step_out), stream)
         self.n_iters += 1

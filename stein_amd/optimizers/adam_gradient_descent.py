@@ -33,17 +33,14 @@ class AdamGradientDescent(AbstractGradientDescent):
     def _state_tensors(self):
         return {"mu": self._mu, "nu": self._nu}
 
-    def _launch(self, theta, phi32, state_dtype, sqnorm_dev, clip_scale, step_out):
+    def _launch(self, theta, phi, state_dtype, sqnorm_dev, clip_scale, step_out):
         first = self.n_iters == 0
-        if self._mu is None or self._mu.shape != phi32.shape or self._mu.dtype != state_dtype:
-            if not first:
-                raise ValueError("phi shape/dtype changed between updates")
-            self._mu = self._new_state(phi32.shape, state_dtype, phi32.device)
-            self._nu = self._new_state(phi32.shape, state_dtype, phi32.device)
+        mu = self._state_for("_mu", phi.shape, state_dtype, phi.device, first)
+        nu = self._state_for("_nu", phi.shape, state_dtype, phi.device, first)
         t = self.n_iters + 1
-        stream = ctypes.c_void_p(torch.cuda.current_stream(phi32.device).cuda_stream)
-        _lib.call("stein_apply_adam", _vp(theta), _vp(phi32), _vp(self._mu), _vp(self._nu), phi32.numel(),
-                  _code(state_dtype), _vp(sqnorm_dev), float(clip_scale), CLIP_THRESHOLD, float(self.learning_rate),
-                  float(self.beta_1), float(self.beta_2), EPS, t, _vp(step_out), stream)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(phi.device).cuda_stream)
+        _lib.call_on(phi.device, "stein_apply_adam", _vp(theta), _vp(phi), _code(phi.dtype), _vp(mu), _vp(nu),
+                     phi.numel(), _code(state_dtype), _vp(sqnorm_dev), float(clip_scale), CLIP_THRESHOLD,
+                     float(self.learning_rate), float(self.beta_1), float(self.beta_2), EPS, t, _vp(step_out), stream)
         self.n_iters = t
         self.learning_rate *= self.decay

@@ -69,8 +69,20 @@ class AbstractSteinSampler:
         if theta is None:
             if not self._shapes:
                 raise ValueError("theta=None needs model_vars={name: shape} to size the particles")
-            gen = np.random.default_rng(seed) if seed is not None else np.random
-            theta = {v: gen.normal(size=[self.n_local] + s) * self.INIT_SCALE for v, s in self._shapes.items()}
+            if seed is not None:
+                # every rank draws the FULL [n, ...] arrays from the same seeded stream and keeps its own rows: the
+                # gathered particles equal the single-rank draw, and no two ranks start from the same particles (with
+                # one stream per rank and the same seed, all ranks would hold identical copies and, SVGD being
+                # deterministic, keep them forever)
+                gen = np.random.default_rng(seed)
+                rank = 0
+                if group is not None:
+                    rank = dist.get_rank(group)
+                lo = rank * self.n_local
+                theta = {v: (gen.normal(size=[self.n_particles] + s) * self.INIT_SCALE)[lo:lo + self.n_local]
+                         for v, s in self._shapes.items()}
+            else:   # the reference's unseeded global stream (abstract_stein_sampler.py:69-74); processes differ
+                theta = {v: np.random.normal(size=[self.n_local] + s) * self.INIT_SCALE for v, s in self._shapes.items()}
         if isinstance(theta, dict):
             packed, self._access = convert_dictionary_to_array(theta)
             if self._shapes is None:

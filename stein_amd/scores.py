@@ -45,7 +45,7 @@ class GlmScore:
         if out is None:
             out = torch.empty_like(theta)
         scale = 1.0 if self.n_train is None else float(self.n_train) / batch
-        _lib.call("stein_score_glm", theta.data_ptr(), n, d, self.kind, self.w_col, self.n_feats, self.alpha_col,
+        _lib.call_on(theta.device, "stein_score_glm", theta.data_ptr(), n, d, self.kind, self.w_col, self.n_feats, self.alpha_col,
                   X.data_ptr(), y.data_ptr(), batch, scale, self.prior_precision, self.gamma_rate, out.data_ptr(),
                   torch.cuda.current_stream(theta.device).cuda_stream)
         return out
@@ -84,7 +84,7 @@ class BnnScore:
             raise ValueError("X must be [batch, %d] and y [batch]" % self.n_in)
         if out is None:
             out = torch.empty_like(theta)
-        _lib.call("stein_score_bnn", theta.data_ptr(), n, d, self.n_in, self.n_hidden, self._cols, X.data_ptr(),
+        _lib.call_on(theta.device, "stein_score_bnn", theta.data_ptr(), n, d, self.n_in, self.n_hidden, self._cols, X.data_ptr(),
                   y.data_ptr(), batch, self.n_train, self.gamma_a, self.gamma_b, out.data_ptr(),
                   torch.cuda.current_stream(theta.device).cuda_stream)
         return out

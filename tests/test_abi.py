@@ -56,7 +56,7 @@ def test_null_pointers_are_refused_before_any_launch():
     assert lib.stein_rownorms(null, 8, 8, _lib.F32, null, null) == _lib.E_BADARG
     assert b"NULL" in lib.stein_last_error()
     assert lib.stein_median_hist_pass(null, 8, 8, 8, 0, null, null, 0, null) == _lib.E_BADARG
-    assert lib.stein_apply_adam(null, null, null, null, 8, _lib.F32, null, 1.0, 10.0, 1e-3, 0.9, 0.999, 1e-8, 1,
+    assert lib.stein_apply_adam(null, null, _lib.F32, null, null, 8, _lib.F32, null, 1.0, 10.0, 1e-3, 0.9, 0.999, 1e-8, 1,
                                 null, null) == _lib.E_BADARG
     total = ctypes.c_size_t(0)
     assert lib.stein_workspace_bytes(8, 8, 8, 7, 0, ctypes.byref(total)) == _lib.E_UNSUPPORTED
@@ -77,3 +77,41 @@ def test_stages_refuse_cpu_tensors():
     t = torch.zeros(8, 4)
     with pytest.raises(RuntimeError, match="no CPU path"):
         HipStages().rownorms(t, 8, 4, torch.zeros(8))
+
+
+def test_calls_run_with_the_tensor_device_current(monkeypatch):
+    """_lib.call_on makes the device of the tensors it is handed the current HIP device for the call (stream 0 and
+    kernel attributes belong to the CURRENT device): no switch when it already is, a scoped switch otherwise."""
+    import torch
+    events = []
+
+    class FakeCtx:
+        def __init__(self, idx):
+            self.idx = idx
+
+        def __enter__(self):
+            events.append(("enter", self.idx))
+
+        def __exit__(self, *a):
+            events.append(("exit", self.idx))
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", FakeCtx)
+    monkeypatch.setattr(_lib, "call", lambda name, *a: events.append(("call", name)))
+    _lib.call_on(torch.device("cuda", 0), "stein_rownorms")
+    assert events == [("call", "stein_rownorms")]
+    events.clear()
+    _lib.call_on(torch.device("cuda", 1), "stein_rownorms")
+    assert events == [("enter", 1), ("call", "stein_rownorms"), ("exit", 1)]
+    events.clear()
+    _lib.call_on(torch.device("cuda"), "stein_rownorms")                # no index: the current device
+    assert events == [("call", "stein_rownorms")]
+
+
+def test_library_reads_no_environment():
+    """The C ABI is steered through its flags only (no hidden global state)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out
+    for src in ("steinhip.hip", "stein_x3.hip", "stein_small.hip", "stein_score.hip", "stein_common.h"):
+        assert "getenv" not in open(os.path.join(ROOT, "stein_amd", "csrc", src)).read()

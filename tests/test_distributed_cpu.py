@@ -135,3 +135,34 @@ def test_uneven_sharding_is_refused():
             SvgdEngine(64, 4, device="cpu", group=FakeGroup(), stages=NumpyStages(_lib.workspace_layout))
     finally:
         d2.get_world_size, d2.get_rank = orig
+
+
+def _worker_seed(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stein_amd.samplers import SteinSampler
+        from stein_amd.optimizers import AdamGradientDescent
+        s = SteinSampler(n, None, AdamGradientDescent(0.1), theta=None, model_vars={"model/w:0": [3, 1], "model/b:0": []},
+                         device="cpu", group=dist.group.WORLD, seed=11, dtype=torch.float64)
+        np.save(os.path.join(out_dir, "seed%d.npy" % rank), s.theta_matrix.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_seeded_initial_particles_are_distinct_across_ranks_and_match_one_rank(tmp_path):
+    """theta=None with a seed: every rank keeps ITS rows of the one seeded [n, d] draw (identical particles on two
+    ranks would stay identical forever -- SVGD is deterministic -- and halve the effective particle count)."""
+    world, n = 2, 12
+    mp.spawn(_worker_seed, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "seed%d.npy" % r)) for r in range(world)]
+    both = np.concatenate(parts, axis=0)
+    assert both.shape == (n, 4)
+    assert len({tuple(row) for row in both}) == n                       # no particle appears twice
+    from stein_amd.samplers import SteinSampler
+    from stein_amd.optimizers import AdamGradientDescent
+    one = SteinSampler(n, None, AdamGradientDescent(0.1), theta=None, model_vars={"model/w:0": [3, 1], "model/b:0": []},
+                       device="cpu", seed=11, dtype=torch.float64)
+    assert np.array_equal(both, one.theta_matrix.numpy())                # the sharded draw IS the single-rank draw
+    assert abs(both.std() - 0.01) < 0.004                                # N(0, 0.01^2), abstract_stein_sampler.py:69-74

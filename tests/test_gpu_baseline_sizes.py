@@ -1,0 +1,210 @@
+"""GPU: every BASELINE.json configuration at its FULL size, compared with reference values.
+
+At these sizes the NumPy oracle cannot produce the whole answer in test time (C3: 7 s per step on 128 threads, C5: 64x
+that and 64 GiB of fp32 distances), so the comparison is per sampled row, which needs only m x n x d work:
+
+  1. the GPU's bandwidth h^2 is proved exact by counting: its two order statistics lo / hi are THE two middle order
+     statistics of the GPU's own n^2 distances (compute_median.py:4-16 semantics), and h^2 = (sqrt(med / ln n))^2
+     bit for bit (abstract_kernel.py:40, squared_exponential_kernel.py:22);
+  2. sampled rows of D (first, middle and last row tile) against the fp64 formula r_i + r_j - 2 <t_i, t_j>;
+  3. the same rows of phi against the fp64 evaluation of abstract_stein_sampler.py:100-105 over ALL n columns
+         K_ij = exp(-D_ij / h^2 / 2)                              squared_exponential_kernel.py:22
+         dK_i = (sum_j K_ij theta_i - sum_j K_ij theta_j) / h^2   squared_exponential_kernel.py:23,32
+         phi_i = (sum_j K_ij g_j + dK_i) / n                      abstract_stein_sampler.py:105
+     with that h^2: relative Frobenius error <= 1e-5 and elementwise |err| <= 1e-5 (|phi|_max + |phi_ij|) -- the
+     north-star tolerance -- over every column, hence every column block of [G | theta].
+
+The fp64 rows are computed with torch on the device (test-side reference of a floating-point kernel; the product never
+uses it).  C5 (n = 131072) runs both as the fused single-GPU call and as rank 0 of an 8-way sharding whose histograms
+are accumulated over all eight row blocks, as the collectives would.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from stein_amd import _lib
+from stein_amd.engine import HipStages, SvgdEngine
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5   # BASELINE.json north star: "within 1e-5 relative fp32"
+
+
+def make_inputs(n, d, device, bf16_round=False):
+    # BASELINE.md section 3 / bench.py: T ~ N(0,1) seed 0, G ~ N(0,1) seed 1, drawn in fp64 then cast
+    T = torch.tensor(np.random.default_rng(0).normal(size=(n, d)), dtype=torch.float32)
+    G = torch.tensor(np.random.default_rng(1).normal(size=(n, d)), dtype=torch.float32)
+    if bf16_round:
+        T, G = T.bfloat16().float(), G.bfloat16().float()
+    return T.to(device), G.to(device)
+
+
+def sample_rows(n_rows, seed, per_tile=22):
+    """rows from the first, a middle and the last 128-row tile of a block of n_rows rows"""
+    rng = np.random.default_rng(seed)
+    tiles = sorted({0, (n_rows // 128) // 2, (n_rows - 1) // 128})
+    rows = []
+    for t in tiles:
+        lo, hi = t * 128, min(n_rows, t * 128 + 128)
+        rows += list(rng.choice(np.arange(lo, hi), size=min(per_tile, hi - lo), replace=False))
+    rows += [0, n_rows - 1]
+    return sorted(set(int(r) for r in rows))
+
+
+def fp64_rows(T, G, rows, h2):
+    """(D rows, phi rows) in fp64 for global row indices `rows`, all n columns."""
+    idx = torch.as_tensor(rows, device=T.device)
+    Ta, Ga = T.double(), G.double()
+    Ti = Ta[idx]
+    ra = (Ta * Ta).sum(1)
+    D = ra[idx][:, None] + ra[None, :] - 2.0 * (Ti @ Ta.T)
+    K = torch.exp(-D / h2 / 2.0)
+    dK = (K.sum(1)[:, None] * Ti - K @ Ta) / h2
+    return D, (K @ Ga + dK) / T.shape[0]
+
+
+def dist_rows(block, rows, n):
+    """rows of the tile-major distance image [rows_padded, ld] (tiles of [128][32]) -> [len(rows), n]"""
+    rp, ld = block.shape
+    v = block.view(rp // 128, ld // 32, 128, 32)
+    idx = torch.as_tensor(rows, device=block.device)
+    return v[idx // 128, :, idx % 128, :].reshape(len(rows), ld)[:, :n]
+
+
+def count_less_leq(images, v, chunk=1 << 28):
+    """(#entries < v, #entries <= v) over flat fp32 images (no padding: n % 128 == 0 here), in bounded chunks"""
+    less = leq = 0
+    for img in images:
+        flat = img.reshape(-1)
+        for o in range(0, flat.numel(), chunk):
+            c = flat[o:o + chunk]
+            less += int((c < v).sum().item())
+            leq += int((c <= v).sum().item())
+    return less, leq
+
+
+def check_exact_bandwidth(images, state_f32, n, h2_reported):
+    """counting proof + bit-exact bandwidth arithmetic; returns h2"""
+    total = n * n
+    med, h2, lo, hi = (state_f32[k].item() for k in (8, 9, 10, 11))
+    k_lo = total // 2 - 1 if total % 2 == 0 else total // 2
+    for v, k in ((lo, k_lo), (hi, total // 2)):
+        less, leq = count_less_leq(images, v)
+        assert less <= k < leq, ("not the order statistic", v, k, less, leq)
+    assert med == np.float32(0.5) * (np.float32(lo) + np.float32(hi))            # n^2 even for every config here
+    bw = np.sqrt(np.float32(med) / np.float32(math.log(n)))
+    assert h2 == np.float32(bw * bw) == h2_reported
+    return h2
+
+
+def check_rows(phi_rows, D_rows, T, G, rows, h2, label, tol=TOL, d_tol=4e-6):
+    D_ref, phi_ref = fp64_rows(T, G, rows, h2)
+    derr = (D_rows.double() - D_ref).abs().max().item() / D_ref.abs().max().item()
+    assert derr <= d_tol, (label, "D", derr)
+    diff = phi_rows.double() - phi_ref
+    rel = (diff.norm() / phi_ref.norm()).item()
+    assert rel <= tol, (label, "phi relative Frobenius error", rel)
+    bound = tol * (phi_ref.abs().max() + phi_ref.abs())
+    assert bool((diff.abs() <= bound).all()), (label, "phi elementwise", (diff.abs() / bound).max().item())
+    # every 128-column block on its own (a wrong out-scale or a dropped block would hide in a global norm)
+    d = phi_ref.shape[1]
+    for c0 in range(0, d, 128):
+        blk = (diff[:, c0:c0 + 128].norm() / phi_ref[:, c0:c0 + 128].norm()).item()
+        assert blk <= 2 * tol, (label, "column block", c0, blk)
+    return rel
+
+
+def run_fused(cuda, n, d, x3, label, dtype=torch.float32, tol=TOL, d_tol=4e-6):
+    bf16 = dtype == torch.bfloat16
+    T, G = make_inputs(n, d, cuda, bf16_round=bf16)
+    eng = SvgdEngine(n, d, device=cuda, x3=x3, dtype=dtype)
+    phi = eng.compute_phi(T.to(dtype), G.to(dtype))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(phi).all())
+    h2 = check_exact_bandwidth([eng.dist], eng.select_state.view(torch.float32), n, eng.h2.item())
+    rows = sample_rows(n, seed=n + d)
+    rel = check_rows(phi[rows], dist_rows(eng.dist, rows, n), T, G, rows, h2, label, tol, d_tol)
+    # |phi|^2 of the whole matrix, reduced on the device
+    assert abs(eng.sqnorm.item() - (phi.double() ** 2).sum().item()) <= 1e-9 * eng.sqnorm.item()
+    return eng, T, G, phi, h2, rel
+
+
+def test_c3_split_path_full_size(cuda):
+    """C3: n=16384, d=256, fp32 inputs, default (split fp16 x 2) GEMM path."""
+    run_fused(cuda, 16384, 256, True, "C3 split")
+
+
+def test_c3_fp32_mfma_path_full_size(cuda):
+    """C3 on the fp32-input MFMA kernels (x3=False)."""
+    run_fused(cuda, 16384, 256, False, "C3 fp32-mfma")
+
+
+def test_c4_full_size(cuda):
+    """C4: n=8192, d=2001 (H=666 BNN flattening: d % 4 != 0, 16 column blocks, ragged last block)."""
+    run_fused(cuda, 8192, 2001, True, "C4 split")
+
+
+def test_c2_bf16_full_size(cuda):
+    """C2: n=4096, d=128, bf16 inputs.  The reference values are the fp64 formulae ON THE bf16-ROUNDED inputs; K is
+    rounded to bf16 inside the kernel (one bf16 product per pair), which sets the tolerance: 4e-3 (SURVEY section 7 item 7:
+    'tolerance set from the oracle run on bf16-rounded inputs, not 1e-5')."""
+    run_fused(cuda, 4096, 128, True, "C2 bf16", dtype=torch.bfloat16, tol=4e-3, d_tol=2e-5)
+
+
+def test_c5_fused_and_rank_block(cuda):
+    """C5: n=131072, d=256.  (a) the fused single-GPU call (64 GiB of distances); (b) rank 0 of the 8-way sharding of
+    BASELINE config 5: its 16384-row block through the staged calls, with the radix-select histograms accumulated over
+    all eight row blocks exactly as the all-reduces would -- the bandwidth must come out the same and the sampled rows
+    must again match the fp64 formulae."""
+    n, d, world = 131072, 256, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 170 * (1 << 30):
+        pytest.fail("C5 needs ~150 GiB of device memory (64 GiB fused + 8 x 8.7 GiB row blocks); %.0f GiB free" % (free / 2**30))
+    eng, T, G, phi, h2_fused, _ = run_fused(cuda, n, d, True, "C5 fused")
+    nl = n // world
+    rows0 = sample_rows(nl, seed=5)                     # rows of rank 0's block (global index == local index)
+    phi_fused_rows = phi[rows0].clone()
+    del eng, phi
+    torch.cuda.empty_cache()
+
+    st = HipStages()
+    flags = _lib.FLAG_X3
+    total, offs, extra = st.workspace_layout(nl, n, d, flags)
+    ld = extra[_lib.WSX_LD_DIST]
+    r = torch.empty(n, device=cuda)
+    st.rownorms(T, n, d, r)
+    blocks = [torch.empty(total, dtype=torch.uint8, device=cuda) for _ in range(world)]
+    planes = blocks[0][offs[_lib.WS_PLANES]:total]      # every rank builds the same planes from the gathered rows
+    st.x3_prepare(T, G, n, d, planes)
+    hist = torch.zeros(_lib.HIST_LEVELS, 2, _lib.HIST_BINS, dtype=torch.int64, device=cuda)
+    sel = torch.zeros(64, dtype=torch.uint8, device=cuda)
+    h2 = torch.zeros(1, device=cuda)
+    med = torch.zeros(1, device=cuda)
+
+    def dist_of(ws):
+        return ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nl * ld * 4].view(torch.float32).view(nl, ld)
+
+    st.median_begin(hist, sel, n * n)
+    for p, ws in enumerate(blocks):                     # level 0 comes out of the distance epilogue of every block
+        st.distance_block(T, r, n, d, p * nl, nl, dist_of(ws), ld, hist0=hist[0], planes=planes)
+    st.median_resolve(hist, 0, n, sel, h2, med)
+    for lv in (1, 2):
+        for ws in blocks:                               # "all-reduce": every block adds into the same histogram
+            st.median_hist_pass(dist_of(ws), ld, nl, n, lv, sel, hist)
+        st.median_resolve(hist, lv, n, sel, h2, med)
+    torch.cuda.synchronize()
+    assert int(hist[0, 0].sum().item()) == n * n        # every entry was counted exactly once
+    h2_blocks = check_exact_bandwidth([dist_of(ws) for ws in blocks], sel.view(torch.float32), n, h2.item())
+    # a non-symmetric row block forms lo*hi and hi*lo in the other order for entries below the diagonal, so single
+    # distances may differ from the symmetric single-rank image in the last bit; the medians agree to that
+    assert abs(h2_blocks - h2_fused) <= 4e-7 * h2_fused, (h2_blocks, h2_fused)
+
+    phi0 = torch.empty(nl, d, device=cuda)
+    sq = torch.zeros(1, dtype=torch.float64, device=cuda)
+    st.kernel_contract(dist_of(blocks[0]), ld, T, G, n, d, 0, nl, h2, phi0, sq, None, blocks[0], planes=planes)
+    torch.cuda.synchronize()
+    check_rows(phi0[rows0], dist_rows(dist_of(blocks[0]), rows0, n), T, G, rows0, h2_blocks, "C5 rank-0 block")
+    assert ((phi0[rows0] - phi_fused_rows).norm() / phi_fused_rows.norm()).item() <= 2e-6
+    assert abs(sq.item() - (phi0.double() ** 2).sum().item()) <= 1e-9 * sq.item()

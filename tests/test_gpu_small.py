@@ -36,7 +36,6 @@ def test_small_path_matches_oracle_and_tiled_kernels(cuda, n, d):
     assert np.abs(dK.double().cpu().numpy() - dKr).max() <= 1e-5 * np.abs(dKr).max()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("STEIN_SMALL", "") == "0", reason="STEIN_SMALL=0 disables the path under test")
 def test_small_path_is_taken_and_left(cuda):
     """n <= 160 takes the one-kernel path (the workspace's distance image stays untouched); larger n or small=False do not."""
     n, d = 64, 8

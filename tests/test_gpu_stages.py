@@ -208,7 +208,7 @@ def test_unaligned_outputs_take_the_scalar_paths(cuda):
 
     def apply(theta, phi, hist):
         stream = ctypes.c_void_p(torch.cuda.current_stream(cuda).cuda_stream)
-        _lib.call("stein_apply_adagrad", ctypes.c_void_p(theta.data_ptr()), ctypes.c_void_p(phi.data_ptr()),
+        _lib.call("stein_apply_adagrad", ctypes.c_void_p(theta.data_ptr()), ctypes.c_void_p(phi.data_ptr()), _lib.F32,
                   ctypes.c_void_p(hist.data_ptr()), theta.numel(), _lib.F32, None, 1.0, 10.0, 1e-2, 0.9, 1e-6, 0, None, stream)
     th_a, hi_a = T.clone(), torch.rand(n, d, device=cuda)
     tb, hb = torch.zeros(n * d + 1, device=cuda), torch.zeros(n * d + 1, device=cuda)

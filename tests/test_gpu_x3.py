@@ -1,5 +1,5 @@
 """GPU: the split-precision ("x3") variant of the two GEMMs -- every fp32 operand as two fp16 terms of its
-power-of-two-scaled value (three products per pair; STEIN_SPLIT_KIND=b3: three bf16 terms, six products) on the 16-bit
+power-of-two-scaled value (three products per pair) on the 16-bit
 matrix cores -- must stay inside the same 1e-5 budget as the fp32-MFMA path and agree with it closely."""
 import numpy as np
 import pytest
@@ -20,8 +20,7 @@ def _inputs(n, d, seed=0):
 
 
 def _split_kind():
-    import os
-    return 3 if os.environ.get("STEIN_SPLIT_KIND", "").startswith("b3") else 2
+    return 2   # two fp16 terms (the three-term bf16 split of round 1 is no longer built)
 
 
 def test_split_planes_reconstruct_fp32(cuda):
