@@ -15,16 +15,29 @@ entry times C5 (n=131072) the same way; a one-GPU run also times the other BASEL
 steps each and reports them under `other_configs` (they are parity-test cases, not the headline value).
 
 value = n * K / (max-over-ranks wall time of the K timed steps), bracketed by barrier + synchronize.
-roofline: the K.[G|theta] contraction kernel (k_phi_x3fs, or k_phi_partial with STEIN_X3=0), algorithmic flops
-4*n_local*n*d per launch (2*n^2*d for K.G plus 2*n^2*d for K.theta), duration from HIP events
+
+roofline (the K.[G|theta] contraction kernel, k_phi_x3fs; k_phi_partial with STEIN_X3=0): duration from HIP events
 recorded around each of its launches on the launching stream inside the timed region (by the library at one rank:
-STEIN_FLAG_TIMING); peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md).
+STEIN_FLAG_TIMING).  `achieved` = the 16-bit MFMA flops the kernel EXECUTES (3 products per fp32 operand pair x the
+algorithmic 4*n_local*n*d: 2*n^2*d for K.G plus 2*n^2*d for K.theta) per second, `peak` = 2.5 PFLOP/s
+dense fp16/bf16 MFMA (MI355X_MICROARCH.md): `frac` is the fraction of the pipe the kernel actually runs on and is
+<= 1.  The algorithmic fp32 flops against the fp32-input MFMA peak (157.3 TFLOP/s, what an fp32 GEMM could reach at
+most) are reported beside it as `fp32_equivalent_*`; the strict fp32-input MFMA kernels are timed under `fp32_path`.
+
+window: the headline step uses the speculative median window (exact, stein_common.h); `window` reports how many of the
+timed steps it delivered the median, and `miss_path` times the same steps with the window disabled (every step pays the
+radix-select passes over D) -- the cost of a miss, driver-timed.
+
+parity_sample_relerr: after the timed region, phi of one more (untimed) call is compared on sampled rows with an fp64
+evaluation of stein/samplers/abstract_stein_sampler.py:100-105 + stein/kernels/squared_exponential_kernel.py:22,32 over
+all n columns (torch fp64 on the device, using the bandwidth the kernels produced).
 cpu_baseline: the NumPy oracle (a port: the reference's TF-1.12 kernel graph cannot run anywhere here) timed
 on the host on a bounded row block of the same workload.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md, chip-level parameters (dense fp32-input MFMA)
-PEAK_BF16_MFMA = 2.5e15        # same table: dense bf16 MFMA
+PEAK_16BIT_MFMA = 2.5e15       # same table: dense bf16 / fp16 MFMA
 WORKLOADS = {
     "c3": dict(n=16384, d=256, name="C3 bayesian-logreg-shaped synthetic block n=16384 d=256 fp32 (roofline config)"),
     "c5": dict(n=131072, d=256, name="C5 n=131072 d=256 fp32, rows sharded over the ranks"),
@@ -80,7 +93,25 @@ class StageClock:
         return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
-def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmup, clock_stages=True):
+def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
+    """Relative Frobenius error of `n_rows` sampled rows of phi_local (rows row0.. of the global matrix) against the
+    fp64 formulae over all n columns, with bandwidth^2 = h2; rows from the first, a middle and the last row tile."""
+    n, nl = T_all.shape[0], phi_local.shape[0]
+    rng = np.random.default_rng(12345)
+    tiles = sorted({0, (nl // 128) // 2, (nl - 1) // 128})
+    rows = sorted({int(r) for t in tiles for r in rng.integers(t * 128, min(nl, t * 128 + 128), size=n_rows // 3)})
+    loc = torch.as_tensor(rows, device=T_all.device)
+    Ta, Ga = T_all.double(), G_all.double()
+    Ti = Ta[loc + row0]
+    ra = (Ta * Ta).sum(1)
+    D = ra[loc + row0][:, None] + ra[None, :] - 2.0 * (Ti @ Ta.T)
+    K = torch.exp(-D / h2 / 2.0)
+    ref = (K @ Ga + (K.sum(1)[:, None] * Ti - K @ Ta) / h2) / n
+    diff = phi_local[loc].double() - ref
+    return float((diff.norm() / ref.norm()).item()), len(rows)
+
+
+def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clock_stages=True, x3=None, window=True):
     from stein_amd import _lib
     from stein_amd.engine import SvgdEngine
     from stein_amd.optimizers import AdagradGradientDescent
@@ -89,7 +120,8 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
     row0 = rank * n_local
     T64, G64, theta, G = make_inputs(n, d, row0, n_local, device, torch)
     bf16 = bool(wl.get("bf16"))      # BASELINE config 2: the kernels see bf16 theta / score; theta's master copy stays fp32
-    eng = SvgdEngine(n, d, device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32)
+    eng = SvgdEngine(n, d, device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32, x3=x3,
+                     window=window)
     gd = AdagradGradientDescent(learning_rate=1e-3, alpha=0.9)
     if bf16:
         G = G.to(torch.bfloat16)
@@ -129,6 +161,8 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
     if world > 1:
         dist.barrier(group=group)
     torch.cuda.synchronize(device)
+    has_window = fused and window and n > 160            # the one-kernel path (n <= 160) keeps no window state
+    stats0 = eng.window_stats() if has_window else (0, 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         step(True)
@@ -141,6 +175,7 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(te.item())
+    stats1 = eng.window_stats() if has_window else (0, 0)
     if fused and clock_stages:
         per_call = _lib.timing_read(steps)
         stages = {k: round(sum(c[k] for c in per_call) / max(1, len(per_call)), 4) for k in _lib.T_STAGES}
@@ -150,8 +185,18 @@ def run_workload(torch, dist, args, wl, device, rank, world, group, steps, warmu
         if "end" in stages:            # interval end -> apply_end is the optimizer apply kernel
             stages["apply"] = stages.pop("end")
     finite = bool(torch.isfinite(theta).all().item())
+    # parity on sampled rows: one more call, untimed, no apply (theta and phi then belong together)
+    cur = feed()
+    phi = eng.compute_phi(cur, G)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        T_all, G_all = eng.T_all.float(), eng.G_all.float()
+    else:
+        T_all, G_all = cur.float(), G.float()
+    relerr, nrows = parity_sample(torch, T_all, G_all, phi, row0, float(eng.h2.item()))
     return dict(n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
-                ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3)
+                ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3, parity_relerr=relerr, parity_rows=nrows,
+                window=dict(timed_steps=stats1[0] - stats0[0], hits=stats1[1] - stats0[1]) if has_window else None)
 
 
 def cpu_baseline(wl, T64, G64, rows):
@@ -176,18 +221,20 @@ def cpu_baseline(wl, T64, G64, rows):
                 seconds=dt)
 
 
-# products per fp32 operand pair in the split path (stein_x3.hip: KIND 2 -> 3 fp16 products, KIND 3 -> 6 bf16 products)
-NPROD = 3
-
-
 def pmc_traffic(workload_key, x3):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/pmc_traffic.json), if any."""
+    """HBM bytes per launch of the dominant kernel as measured with rocprofv3 --pmc (separate passes, FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950) and committed under profiles/.  Counters cannot be read from inside
+    this process; the entry says which file and which commit the number comes from."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(workload_key, {}).get("k_phi_x3fs_hbm_bytes" if x3 else "k_phi_partial_hbm_bytes")
+            rec = json.load(f)
+        val = rec.get(workload_key, {}).get("k_phi_x3fs_hbm_bytes" if x3 else "k_phi_partial_hbm_bytes")
+        if val is None:
+            return None, None
+        return val, "profiles/pmc_traffic.json <- %s, measured at commit %s" % (rec.get("source", "?"), rec.get("commit", "?"))
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -203,6 +250,7 @@ def main():
     ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
     ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief C1 / C2 / C4 timings (one GPU)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the miss-path and fp32-path timings (one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -238,16 +286,35 @@ def main():
     if args.n or args.d:
         wl["n"], wl["d"] = args.n or wl["n"], args.d or wl["d"]
         wl["name"] = "custom n=%d d=%d fp32" % (wl["n"], wl["d"])
-    res = run_workload(torch, dist, args, wl, device, rank, world, group, args.steps, args.warmup)
+    env_x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
+    res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup)
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
     value = n * args.steps / res["elapsed"]
-    global NPROD
-    if wl.get("bf16"):
-        NPROD = 1               # bf16 inputs: one bf16 product per pair
+    nprod = (1 if wl.get("bf16") else 3) if res["x3"] else 1     # 16-bit MFMA products per operand pair
     k_ms = res["stages"].get("contract")
     flops = 4.0 * nl * n * d
-    achieved = flops / (k_ms * 1e-3) if k_ms else None
+    alg = flops / (k_ms * 1e-3) if k_ms else None
+    traffic, traffic_src = pmc_traffic(args.workload, res["x3"]) if world == 1 else (None, None)
+    if res["x3"]:
+        roof = {
+            "kernel": "k_phi_x3fs (exp + split-precision MFMA K.[G|theta] contraction, %d 16-bit products per operand pair)" % nprod,
+            "bound": "mfma", "achieved": nprod * alg / 1e12 if alg else None, "peak": PEAK_16BIT_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": nprod * alg / PEAK_16BIT_MFMA if alg else None,
+            "note": "achieved = EXECUTED 16-bit MFMA flops (%d products x the algorithmic 4 n_local n d) / mean kernel time, "
+                    "against the dense fp16/bf16 MFMA peak: the fraction of the pipe the kernel runs on" % nprod,
+            "fp32_equivalent_tflops": alg / 1e12 if alg else None,
+            "fp32_equivalent_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA if alg else None,
+        }
+    else:
+        roof = {
+            "kernel": "k_phi_partial (exp + fp32-input MFMA K.[G|theta] contraction)",
+            "bound": "mfma", "achieved": alg / 1e12 if alg else None, "peak": PEAK_FP32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": alg / PEAK_FP32_MFMA if alg else None,
+            "note": "fp32-input MFMA kernel: algorithmic = executed flops",
+        }
+    roof.update({"algorithmic_flops_per_launch": flops, "executed_flops_per_launch": nprod * flops, "ms_per_launch": k_ms,
+                 "traffic": traffic, "traffic_source": traffic_src})
     out = {
         "metric": "SVGD particle-updates/sec",
         "value": value,
@@ -268,28 +335,39 @@ def main():
                    if world > 1 else "single GPU"},
         "element_updates_per_s": value * d,
         "pair_interactions_per_s": value * n,
-        "roofline": {
-            "kernel": ("k_phi_x3fs (exp + split-precision MFMA K.[G|theta] contraction, %d 16-bit products per fp32 pair)"
-                       % NPROD if res["x3"] else "k_phi_partial (exp + fp32-input MFMA K.[G|theta] contraction)"),
-            "bound": "mfma", "achieved": achieved / 1e12 if achieved else None, "peak": PEAK_FP32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA if achieved else None,
-            "flops_per_launch": flops, "ms_per_launch": k_ms,
-            "traffic": pmc_traffic(args.workload, res["x3"]) if world == 1 else None,
-            "note": ("achieved = ALGORITHMIC fp32 flops (4 n_local n d) / kernel time against the dense fp32-input MFMA "
-                     "peak, as SURVEY 7/8(d) prescribes for split-precision emulation; the kernel executes %dx that many "
-                     "16-bit MFMA flops" % NPROD if res["x3"] else "fp32-input MFMA kernel"),
-            "executed_mfma_tflops": (NPROD if res["x3"] else 1.0) * achieved / 1e12 if achieved else None,
-            "frac_of_executed_dtype_peak": ((NPROD * achieved / PEAK_BF16_MFMA) if res["x3"] else achieved / PEAK_FP32_MFMA)
-            if achieved else None,
-        },
-        "gemm_path": ({1: "bf16 inputs (1 product)", 3: "split fp16 x 2 (3 products)", 6: "split bf16 x 3 (6 products)"}[NPROD]) if res["x3"] else "fp32 mfma",
+        "roofline": roof,
+        "gemm_path": ({1: "bf16 inputs (1 product)", 3: "split fp16 x 2 (3 products)"}[nprod]) if res["x3"] else "fp32 mfma",
         "stage_ms": {k: round(v, 4) for k, v in res["stages"].items()},
+        "window": res["window"],
         "full_step_tflops": 6.0 * nl * n * d / (ms_per_step * 1e-3) / 1e12,
         "finite": res["finite"],
+        "parity_sample_relerr": res["parity_relerr"],
+        "parity_sample_rows": res["parity_rows"],
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, res["T64"], res["G64"], args.cpu_rows)
     del res
+
+    # one GPU: what the headline does not show -- a step whose window misses, and the strict fp32-input MFMA kernels
+    if world == 1 and not args.no_variants and not wl.get("bf16") and env_x3:
+        torch.cuda.empty_cache()
+        rm = run_workload(torch, dist, wl, device, rank, world, group, 10, 3, window=False)
+        out["miss_path"] = {"what": "the same step with the speculative median window disabled: every step runs the "
+                                    "radix-select passes over D (what a window miss costs)",
+                            "steps": 10, "ms_per_step": rm["elapsed"] / 10 * 1e3,
+                            "stage_ms": {k: round(v, 4) for k, v in rm["stages"].items()},
+                            "parity_sample_relerr": rm["parity_relerr"]}
+        del rm
+        torch.cuda.empty_cache()
+        rf = run_workload(torch, dist, wl, device, rank, world, group, 5, 2, x3=False)
+        kf = rf["stages"].get("contract")
+        out["fp32_path"] = {"what": "the same step on the fp32-input MFMA kernels (x3=False): exact k-ordered fmaf chains",
+                            "steps": 5, "ms_per_step": rf["elapsed"] / 5 * 1e3,
+                            "stage_ms": {k: round(v, 4) for k, v in rf["stages"].items()},
+                            "contract_ms": kf, "contract_tflops": flops / (kf * 1e-3) / 1e12 if kf else None,
+                            "contract_frac_of_fp32_mfma_peak": flops / (kf * 1e-3) / PEAK_FP32_MFMA if kf else None,
+                            "parity_sample_relerr": rf["parity_relerr"]}
+        del rf
 
     if args.secondary != "none" and args.secondary != args.workload:
         wl2 = WORKLOADS[args.secondary]
@@ -297,7 +375,7 @@ def main():
         free = torch.cuda.mem_get_info(device)[0]
         if need < free * 0.9:
             torch.cuda.empty_cache()
-            r2 = run_workload(torch, dist, args, wl2, device, rank, world, group, args.secondary_steps, 3)   # 3 warm-up steps: the median predictor needs two medians of history
+            r2 = run_workload(torch, dist, wl2, device, rank, world, group, args.secondary_steps, 3)   # 3 warm-up steps: the median predictor needs two medians of history
             k2 = r2["stages"].get("contract")
             f2 = 4.0 * r2["n_local"] * r2["n"] * r2["d"]
             out["secondary"] = {
@@ -305,23 +383,37 @@ def main():
                 "ms_per_step": r2["elapsed"] / args.secondary_steps * 1e3,
                 "value": r2["n"] * args.secondary_steps / r2["elapsed"], "unit": "particle-updates/s",
                 "scaling": "strong (fixed n=%d)" % r2["n"],
-                "contract_tflops": f2 / (k2 * 1e-3) / 1e12 if k2 else None,
+                "contract_executed_tflops": 3 * f2 / (k2 * 1e-3) / 1e12 if k2 else None,
+                "contract_frac_of_16bit_mfma_peak": 3 * f2 / (k2 * 1e-3) / PEAK_16BIT_MFMA if k2 else None,
                 "stage_ms": {k: round(v, 4) for k, v in r2["stages"].items()}, "finite": r2["finite"],
+                "window": r2["window"], "parity_sample_relerr": r2["parity_relerr"],
             }
+            del r2
     # one GPU: the remaining BASELINE configs (parity-test cases, timed briefly for the record; not the headline value)
     if world == 1 and args.workload == "c3" and not args.no_other_configs:
         others = {}
         for key in ("c1", "c2", "c4"):
             torch.cuda.empty_cache()
-            ro = run_workload(torch, dist, args, dict(WORKLOADS[key]), device, rank, world, group, 20, 3, clock_stages=False)
+            # the step time without stage events in the loop (at these sizes the event records are not free), then a
+            # short run with them for the stage split
+            ro = run_workload(torch, dist, dict(WORKLOADS[key]), device, rank, world, group, 20, 3, clock_stages=False)
+            rs = run_workload(torch, dist, dict(WORKLOADS[key]), device, rank, world, group, 8, 3)
             others[key] = {"workload": WORKLOADS[key]["name"], "n": ro["n"], "d": ro["d"], "steps": 20,
                            "ms_per_step": ro["elapsed"] / 20 * 1e3, "value": ro["n"] * 20 / ro["elapsed"],
-                           "unit": "particle-updates/s", "finite": ro["finite"]}
+                           "unit": "particle-updates/s", "finite": ro["finite"],
+                           "stage_ms": {k: round(v, 4) for k, v in rs["stages"].items()},
+                           "window": ro["window"], "parity_sample_relerr": ro["parity_relerr"]}
+            del rs
             if not args.no_cpu_baseline:     # the NumPy oracle on the same inputs (C4: a bounded row block)
                 others[key]["cpu_baseline"] = cpu_baseline(WORKLOADS[key], ro["T64"], ro["G64"],
                                                            2048 if key == "c4" else ro["n"])
             del ro
         out["other_configs"] = others
+    try:
+        out["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                       text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        out["commit"] = None
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -93,8 +93,8 @@ class NumpyStages:
         self._st = None
         self._partial = None
 
-    def workspace_layout(self, n_local, n, d, flags=0):
-        return self._layout(n_local, n, d, 0, flags)
+    def workspace_layout(self, n_local, n, d, flags=0, dtype=0):
+        return self._layout(n_local, n, d, dtype, flags)
 
     def x3_prepare(self, T, G, n, d, planes):
         pass   # the split-bf16 operand planes are a device-side detail; the model multiplies in fp64

@@ -1,0 +1,28 @@
+"""Diagnostic builds of the library: python scratch/build_variant.py <name> [-DFLAG ...] -> scratch/lib_<name>.so
+Recompiles the two translation units that hold the MFMA kernels with the extra flags and links them with the shipped
+objects of the other two (run __graft_entry__.build() first).  Ablation / stamp builds only; nothing ships from here."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+def main():
+    name, flags = sys.argv[1], sys.argv[2:]
+    ge.build()
+    tmp = os.path.join(ge.OBJDIR, "variant_" + name)
+    os.makedirs(tmp, exist_ok=True)
+    objs, procs = [], []
+    for src in ge.SRCS:
+        base = os.path.basename(src)
+        if base in ("stein_x3.hip", "steinhip.hip"):
+            obj = os.path.join(tmp, base + ".o")
+            procs.append(subprocess.Popen([ge._hipcc()] + ge.HIPCC_FLAGS + flags + ["-c", src, "-o", obj]))
+        else:
+            obj = os.path.join(ge.OBJDIR, base + ".o")
+        objs.append(obj)
+    for p in procs:
+        if p.wait(): raise SystemExit("compile failed")
+    out = os.path.join(ROOT, "scratch", "lib_%s.so" % name)
+    subprocess.run([ge._hipcc()] + ge.LINK_FLAGS + objs + ["-o", out], check=True)
+    print(out)
+if __name__ == "__main__":
+    main()

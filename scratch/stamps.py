@@ -1,26 +1,40 @@
-import ctypes, os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/stein_amd") else os.getcwd())
+"""Per-phase cycles of the split contraction kernel (k_phi_x3fs) and the clock the chip holds inside it.
+-DSTEIN_STAMPS build (scratch/build_variant.py stamps -DSTEIN_STAMPS); usage: STAMPLIB=lib_stamps.so python scratch/stamps.py n d
+The clock is read after ~2 s of back-to-back steps on random data (MI355X_MICROARCH.md, DVFS give-back item 6)."""
+import ctypes, os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stein_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPLIB", "libsteinhip_stamps.so"))
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPLIB", "lib_stamps.so"))
 from stein_amd.engine import SvgdEngine
 lib = _lib.load()
+lib.stein_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+lib.stein_debug_clock.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 n, d = int(sys.argv[1]), int(sys.argv[2])
 T = torch.randn(n, d, device="cuda"); G = torch.randn(n, d, device="cuda")
 eng = SvgdEngine(n, d, device="cuda", x3=True)
-eng.compute_phi(T, G); torch.cuda.synchronize()
-buf = (ctypes.c_uint64 * 8)()
-lib.stein_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+t0 = time.time()
+while time.time() - t0 < 2.0:
+    for _ in range(50): eng.compute_phi(T, G)
+    torch.cuda.synchronize()
+buf = (ctypes.c_uint64 * 8)(); clk = (ctypes.c_uint64 * 2)()
+acc = np.zeros(8); cacc = np.zeros(2)
 def mark(label):        # the staged calls: reset the counters right before the contraction, read them right after
     if label == "contract":
-        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1)
+        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1); lib.stein_debug_clock(clk, 1)
     elif label == "finish":
-        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0)
-eng.compute_phi(T, G, mark=mark); torch.cuda.synchronize()
-v = np.array(list(buf), dtype=np.float64)
+        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0); lib.stein_debug_clock(clk, 0)
+        acc[:] += np.array(list(buf), dtype=np.float64); cacc[:] += np.array(list(clk), dtype=np.float64)
+reps = 8
+for _ in range(reps):
+    for _ in range(30): eng.compute_phi(T, G)          # keep the chip loaded between the measured launches
+    eng.compute_phi(T, G, mark=mark)
+torch.cuda.synchronize()
+v = acc; clk = cacc
 nb = v[7]
 jt = (n + 31) // 32
-names = ["P:produce", "P:issue", "P:barrier", "C4:mma", "C4:barrier", "C8:total", "C8:bwait"]
-print("blocks", nb, "split", eng.split, "ktiles/block", jt / eng.split)
+names = ["P:exp/split/LDS", "P:wait D loads", "P:barrier", "C4:mma", "C4:barrier", "C8:total", "C8:bwait"]
+print("workgroups", nb / reps, "split", eng.split, "k tiles per workgroup", jt / eng.split)
 for k, nm in enumerate(names):
-    print("%-15s %8.1f ticks per k-tile (100 MHz ticks? s_memtime = shader clock)" % (nm, v[k] / nb / (jt / eng.split)))
-
+    print("%-17s %8.1f shader cycles per k tile" % (nm, v[k] / nb / (jt / eng.split)))
+if clk[1]:
+    print("in-kernel clock of the contraction (delta s_memtime / delta s_memrealtime x 100 MHz): %.3f GHz" % (clk[0] / clk[1] * 0.1))

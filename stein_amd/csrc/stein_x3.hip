@@ -72,6 +72,12 @@ __device__ u64 g_stamps[8];
     st_last = now_;                                                               \
     __builtin_amdgcn_sched_barrier(0);                                            \
   } while (0)
+__device__ u64 g_clock[2];   // sums over the sampled waves of (shader-clock ticks, 100 MHz real-time ticks) inside the contraction's main loop
+extern "C" int stein_debug_clock(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock), sizeof(u64) * 2) != hipSuccess) return -1;
+  if (reset) { u64 z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 extern "C" int stein_debug_stamps(u64* host_out, int reset) {
   if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(u64) * 8) != hipSuccess) return -1;
   if (reset) { u64 z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
@@ -388,6 +394,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
   unsigned char* Bs = smem + OP;
   int tile_m, tile_n;
   if (!distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n)) return;
+#ifdef STEIN_STAGGER   // (experiment build: de-phase the workgroups that share a CU)
+  if (blockIdx.x < 768)
+    for (int i = 0; i < (int)(blockIdx.x / 256) * STEIN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const long arow0 = row0 + (long)tile_m * BM, brow0 = (long)tile_n * BN;
@@ -421,17 +431,41 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
     STAMP(0);   // waiting for the tile's loads + LDS stores
     __syncthreads();
     STAMP(1);   // barrier
+#ifndef STEIN_ABL_NOLOAD   // (ablation builds: scratch/build_variant.py; never shipped)
     if (kt + 1 < ntk) {
       t3_load<NP>(pa0, pa1, kt + 1, ra);
       t3_load<NP>(pb0, pb1, kt + 1, rb);
     }
+#endif
+#ifndef STEIN_ABL_NOMFMA
     x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
+#else
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(acc[i][j][e]));
+#endif
     STAMP(2);   // load issue + fragment reads + MFMAs
     __syncthreads();
     STAMP(1);
   }
+#ifndef STEIN_ABL_NOEPI
   distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
                          two_s_v, spec, spec_buf);
+#else
+  {
+    float sum = two_s_v + pf.norm;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+    D[d_index(tile_m * BM + (t >> 1), tile_n * BN + (t & 1), ldD >> 5)] = sum;
+  }
+#endif
 #ifdef STEIN_STAMPS
   STAMP(3);     // epilogue
   if (t == 0) {
@@ -458,6 +492,32 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
 //   block cb covers pair (2cb, 2cb+1); consumer wave cw takes half cw >> 2, 32-column block cw & 3.
 // ------------------------------------------------------------------------------------------------
 constexpr int FS_THREADS = 768;
+
+// ---- streamed loads with hand-counted waits ---------------------------------------------------------------------
+// The contraction's two roles each keep global loads in flight ACROSS loop iterations (D tiles four k tiles ahead, V
+// fragments one k tile ahead).  hipcc counts its own loads' s_waitcnt conservatively across a loop back-edge: in front
+// of the first use of a tile it emitted vmcnt(3) ... vmcnt(0), which also waits for the loads issued a moment earlier
+// for LATER tiles -- every k tile then paid a full memory latency and the "prefetch" was one tile deep at best (round-2
+// finding: the producers needed 1900 cycles per k tile for 500 cycles of work, the matrix waves idled 40 % of the time).
+// So these loads are inline asm, which the compiler neither counts nor waits for (cdna_hip_programming.md 5.7), and the
+// waits are written by hand: stream_wait<N> lets the N youngest loads of the wave stay in flight; the scheduling fence
+// behind it keeps every use of the loaded registers below the wait (an MFMA is not a memory operation: "memory" alone
+// does not hold it, cdna_hip_programming.md 5.4 rule 18).  The registers are deliberately NOT operands of the wait: tied
+// "+v" operands made the compiler copy the (not yet landed) registers in front of the wait.  Loads complete in issue
+// order per wave.  After every change here: check in the .s that no v_mov / spill touches a destination register between
+// its load and its wait.
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_load16(f32x4g& dst, const void* base /* wave-uniform */, u32 byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base));
+}
+__device__ __forceinline__ void stream_load16(u32x4& dst, const void* base /* wave-uniform */, u32 byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base));
+}
+template <int N>
+__device__ __forceinline__ void stream_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 // k tiles per pipeline stage (even: tile parity picks the register set) and the LDS of one k tile (NP planes, packed)
 template <int NP> struct FsGeom {
   static constexpr int KT = 4;                        // 2 stages x KT x NP x 8 KB: 128 KB (NP 2), 64 KB (NP 1)
@@ -484,6 +544,25 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
   const int jbeg = z * jchunk;
   const int jend = min(n, jbeg + jchunk);
   const int ntile = jend > jbeg ? (jend - jbeg + BK - 1) / BK : 0;
+  // Visit order of the k tiles inside a pipeline stage.  The `cblocks` workgroups of a row tile all stream the same D row
+  // block.  Walking it in step, each of them waits out the full HBM latency of every tile (a request that arrives while
+  // another workgroup's fill of the same line is in flight waits for that fill), and a CU holds only ~25 KB of misses in
+  // flight.  So workgroup cb walks the FS_KT tiles of a full stage rotated by rot = cb * FS_KT / min(cblocks, FS_KT): at any
+  // time the workgroups of a row tile request DIFFERENT tiles, each tile is pulled from HBM by one of them and found in
+  // the XCD's L2 a tile or two later by the others (a lag of whole stages, 64 KB per workgroup, did not survive in the
+  // 4 MB L2 that 32 CUs share: measured slower).  Slot u of the LDS stage holds tile stage * FS_KT + ((u + rot) % FS_KT);
+  // the partial last stage keeps its order.  (The order of the k tiles inside the fp32 accumulation changes with it --
+  // deterministically.)
+  const int nstage = (ntile + FS_KT - 1) / FS_KT;
+#ifdef STEIN_ROT   // (experiment builds)
+  const int rot = (cb * STEIN_ROT) % FS_KT;
+#else
+  const int rot = (cb % FS_KT) * (cblocks >= FS_KT ? 1 : FS_KT / cblocks) % FS_KT;
+#endif
+  auto tile_at = [&](int stage, int u) {     // u may run past the stage: u >= FS_KT continues in the next stage
+    const int st2 = stage + u / FS_KT, u2 = u % FS_KT;
+    return st2 * FS_KT + ((st2 + 1) * FS_KT <= ntile ? ((u2 + rot) & (FS_KT - 1)) : u2);
+  };
 
   const int t = threadIdx.x;
   // The two roles run separate loops (so neither carries the other's registers) with the same number of
@@ -491,12 +570,15 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
   if (t < 256) {
     // ================================ PRODUCER ================================
     const int pt = t;
+#ifdef STEIN_ABL_P_PRIO
+    __builtin_amdgcn_s_setprio(STEIN_ABL_P_PRIO);
+#endif
     const int lr = pt >> 3, lc = (pt & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     // PD register sets (tile index mod PD picks the set): the loads of tile t + PD are issued as soon as tile t has been
     // turned into LDS data.  D streams from HBM (never re-used), so the loads need several tiles of lead
     constexpr int PD = FS_KT;   // 4; FS_KT % PD == 0 keeps the set index static
-    float4 rd[PD][4];
+    f32x4g rd[PD][4];
     u32 doff[4];
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
     constexpr float pofs = (float)SplitTraits<NP>::pexp;        // P carries 2^pexp (undone by the out-scales)
@@ -505,40 +587,83 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #pragma unroll
     for (int p = 0; p < 4; ++p) doff[p] = (u32)((lr + 32 * p) * DT_COLS + lc);
     const float* __restrict__ drow = D + (size_t)tile_m * (ldD >> 5) * DT_ELEMS;
-    auto issue_loads = [&](int j0, float4 (&rd)[4]) {
+    auto issue_loads = [&](int j0, f32x4g (&rd)[4]) {
       const float* tile = drow + (size_t)(j0 >> 5) * DT_ELEMS;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const float4*>(tile + doff[p]);
+      for (int p = 0; p < 4; ++p) stream_load16(rd[p], tile, doff[p] * 4u);
+    };
+    // before tile number v (in visit order) of the ntile is turned into LDS data: its 4 loads must have landed, the loads
+    // of the up to three later tiles already requested (4 each) stay in flight
+    auto wait_loads = [&](int v, f32x4g (&rd)[4]) {
+      const int later = ntile - v - 1;
+      (void)rd;
+      if (later >= 3) stream_wait<12>();
+      else if (later == 2) stream_wait<8>();
+      else if (later == 1) stream_wait<4>();
+      else stream_wait<0>();
     };
     // registers of tile j0 -> LDS stage `buf`
-    auto produce = [&](int j0, unsigned char* buf, const float4 (&rd)[4]) {
+    // One k tile: 16 entries per thread, done phase by phase over all 16 (fma, exp, row sums, hi terms, residuals, lo
+    // terms, stores) with scheduling fences between the phases.  Entry by entry the stream is a chain of dependent
+    // instructions (cvt -> fma_mix -> cvt -> store), and next to two matrix waves on the SIMD a dependent instruction waits
+    // for the next free issue window: measured ~16 cycles per instruction.  Sixteen independent instructions per phase
+    // fill the windows.
+    auto produce = [&](int j0, unsigned char* buf, const f32x4g (&rd)[4]) {
       const bool full = j0 + BK <= jend;
+      float q[4][4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float4 q4;
-        q4.x = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].x, pofs));
-        q4.y = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].y, pofs));
-        q4.z = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].z, pofs));
-        q4.w = __builtin_amdgcn_exp2f(__builtin_fmaf(cexp, rd[p].w, pofs));
-        if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
-          const int j = j0 + lc;
-          q4.x = (j + 0 < jend) ? q4.x : 0.f;
-          q4.y = (j + 1 < jend) ? q4.y : 0.f;
-          q4.z = (j + 2 < jend) ? q4.z : 0.f;
-          q4.w = (j + 3 < jend) ? q4.w : 0.f;
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[p][e] = __builtin_fmaf(cexp, rd[p][e], pofs);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef STEIN_ABL_P_NOEXP   // (ablation build: no transcendental)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[p][e] = __builtin_amdgcn_exp2f(q[p][e]);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
+        const int j = j0 + lc;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[p][e] = (j + e < jend) ? q[p][e] : 0.f;
+      }
+      if (NP >= 2) {
+        u32 hi[4][2], lo[4][2];
+        float r[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rs[p] += (q[p][0] + q[p][1]) + (q[p][2] + q[p][3]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { hi[p][0] = cvt_pk_f16(q[p][0], q[p][1]); hi[p][1] = cvt_pk_f16(q[p][2], q[p][3]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          r[p][0] = f16_resid_lo(hi[p][0], q[p][0]); r[p][1] = f16_resid_hi(hi[p][0], q[p][1]);
+          r[p][2] = f16_resid_lo(hi[p][1], q[p][2]); r[p][3] = f16_resid_hi(hi[p][1], q[p][3]);
         }
-        unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
-        if (NP >= 2) {
-          rs[p] += (q4.x + q4.y) + (q4.z + q4.w);
-          u32 wa[3], wb[3];
-          split_pair<NP>(q4.x, q4.y, wa);
-          split_pair<NP>(q4.z, q4.w, wb);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int s = 0; s < NP; ++s) *reinterpret_cast<uint2*>(dst + s * XPLANE) = make_uint2(wa[s], wb[s]);
-        } else {
+        for (int p = 0; p < 4; ++p) { lo[p][0] = cvt_pk_f16(r[p][0], r[p][1]); lo[p][1] = cvt_pk_f16(r[p][2], r[p][3]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
+#ifdef STEIN_ABL_P_NOLDSW   // (ablation build: the producers write nothing to LDS)
+          asm volatile("" :: "v"(hi[p][0]), "v"(hi[p][1]), "v"(lo[p][0]), "v"(lo[p][1]), "v"(dst));
+#else
+          *reinterpret_cast<uint2*>(dst) = make_uint2(hi[p][0], hi[p][1]);
+          *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(lo[p][0], lo[p][1]);
+#endif
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
           // bf16 operands: K is rounded to bf16 once and BOTH uses of it (K.theta in the MFMA and rowsum(K) here) see
           // the rounded value, so the repulsion term sum_j K_ij (theta_i - theta_j) stays consistent
-          const u32 h0 = cvt_pk_bf16(q4.x, q4.y), h1 = cvt_pk_bf16(q4.z, q4.w);
+          unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;
+          const u32 h0 = cvt_pk_bf16(q[p][0], q[p][1]), h1 = cvt_pk_bf16(q[p][2], q[p][3]);
           rs[p] += (__uint_as_float(h0 << 16) + __uint_as_float(h0 & 0xffff0000u)) +
                    (__uint_as_float(h1 << 16) + __uint_as_float(h1 & 0xffff0000u));
           *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
@@ -552,18 +677,25 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #endif
     // A pipeline stage holds FS_KT consecutive k tiles, so the workgroup synchronises once per FS_KT tiles.  Tile
     // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
-    const int nstage = (ntile + FS_KT - 1) / FS_KT;
 #pragma unroll
     for (int u = 0; u < PD; ++u)
-      if (u < ntile) issue_loads(jt(u), rd[u]);
+      if (tile_at(0, u) < ntile) issue_loads(jt(tile_at(0, u)), rd[u]);
+    // stage st: turn the registers of its tiles into LDS data (slot u <- tile_at(st, u)), then request the next stage's
     auto produce_stage = [&](int st, unsigned char* buf) {
-      const int tile = st * FS_KT;
 #pragma unroll
       for (int u = 0; u < FS_KT; ++u) {
-        if (tile + u < ntile) {
-          produce(jt(tile + u), buf + u * FS_KTB, rd[u % PD]);
-          if (tile + u + PD < ntile) issue_loads(jt(tile + u + PD), rd[u % PD]);
+        const int tile_u = tile_at(st, u), next_u = tile_at(st + 1, u);
+        if (tile_u < ntile) {
+          STAMP(0);
+          wait_loads(st * FS_KT + u, rd[u % PD]);   // (tiles are requested in visit order: position = st * FS_KT + u)
+          STAMP(1);   // diagnostic builds: how long the producer waited for this tile's D loads
+          produce(jt(tile_u), buf + u * FS_KTB, rd[u % PD]);
         }
+#if defined(STEIN_ABL_P_HALFLOAD)   // (ablation build: only the workgroups of column block 0 stream D)
+        if (cb == 0 && next_u < ntile) issue_loads(jt(next_u), rd[u % PD]);
+#elif !defined(STEIN_ABL_P_NOLOAD)   // (ablation build: the producers re-use the first tiles' registers)
+        if (next_u < ntile) issue_loads(jt(next_u), rd[u % PD]);
+#endif
       }
     };
     produce_stage(0, smem);
@@ -577,7 +709,11 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       STAMP(2);   // barrier
     }
 #ifdef STEIN_STAMPS
+#ifdef STEIN_ABL_P_HALFLOAD
+    if (t == 0 && cb == 0) {
+#else
     if (t == 0) {
+#endif
       for (int k = 0; k < 3; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
       atomicAdd(&g_stamps[7], 1ull);
     }
@@ -601,9 +737,18 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     const int l15 = lane & 15, lq = lane >> 4;
     const int g = 2 * cb + (cw >> 2);   // this wave's 128-column block of [G | theta]
     // B fragment of (k tile kt, plane s, 16-column block jb): vb + ((kt * 3 + s) * 4096 + jb * 512) elements
-    const u16* __restrict__ vb = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E
-                                              : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E) +
-                                 (size_t)(jbeg >> 5) * 3 * XTILE_E + (cw & 3) * 1024 + lane * 8;
+    // (wave-uniform part, made provably so for the "s" operand of the streamed loads; per-lane byte offsets boff below)
+    const u16* vb_wave = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E
+                                      : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E) +
+                         (size_t)(jbeg >> 5) * 3 * XTILE_E + (cw & 3) * 1024;
+    const u16* __restrict__ vb = reinterpret_cast<const u16*>(
+        ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)((unsigned long long)vb_wave >> 32)) << 32) |
+        (unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(unsigned long long)vb_wave));
+    u32 boff[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) boff[j][s] = (u32)(lane * 8 + s * XTILE_E + j * 512) * 2u;
     const int aoff = l15 * XROW + pswz(l15, lq);   // A fragment of 16-row block ib, plane s: + ib * 1024 + s * XPLANE
     f32x4 acc[8][2];
 #pragma unroll
@@ -618,13 +763,25 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < NP; ++s) b[j][s] = *reinterpret_cast<const u32x4*>(src + s * XTILE_E + j * 512);
+        for (int s = 0; s < NP; ++s) stream_load16(b[j][s], src, boff[j][s]);
+    };
+    // before the MFMAs of a tile: its 2 NP fragment loads must have landed; `younger`: the next tile's 2 NP loads have
+    // been requested already and stay in flight
+    auto wait_b = [&](bool younger, u32x4 (&b)[2][3]) {
+      (void)b;
+      if (younger) stream_wait<2 * NP>();
+      else stream_wait<0>();
     };
     // A fragments are read one 16-row block ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
     // all 24 reads (96 registers) to the top of the tile
     auto read_a = [&](const unsigned char* As, int i, u32x4 (&a)[3]) {
+#ifdef STEIN_ABL_C_NOLDS   // (ablation build: the matrix waves read no LDS)
+#pragma unroll
+      for (int s = 0; s < NP; ++s) { a[s] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(a[s])); }
+#else
 #pragma unroll
       for (int s = 0; s < NP; ++s) a[s] = *reinterpret_cast<const u32x4*>(As + aoff + i * 16 * XROW + s * XPLANE);
+#endif
     };
     auto mma_tile = [&](const unsigned char* As, const u32x4 (&b)[2][3]) {
       u32x4 a[2][3];
@@ -633,36 +790,51 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       for (int i = 0; i < 8; ++i) {
         if (i + 1 < 8) read_a(As, i + 1, a[(i + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef STEIN_ABL_C_NOMFMA   // (ablation build: the matrix waves read their operands and issue no MFMA)
+#pragma unroll
+        for (int s = 0; s < NP; ++s) asm volatile("" :: "v"(a[i & 1][s]), "v"(b[0][s]), "v"(b[1][s]));
+#else
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = x3_products16<NP>(a[i & 1], b[j], acc[i][j]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (ntile > 0) load_b(0, bX);
+    if (ntile > 0) load_b(tile_at(0, 0), bX);
+#ifdef STEIN_ABL_C_NOVLOAD
+    if (ntile > 0) load_b(tile_at(0, 0), bY);
+#endif
     __syncthreads();
 #ifdef STEIN_STAMPS
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
     u64 st_last = __builtin_amdgcn_s_memtime();
+    const u64 clk0 = st_last, rt0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    const int nstage = (ntile + FS_KT - 1) / FS_KT;
     for (int st = 0; st < nstage; ++st) {
       STAMP(5);
       const unsigned char* As = smem + (st & 1) * FS_STAGE;
-      const int tile = st * FS_KT;
-#ifdef STEIN_STAMPS
-#define BWAIT() do { STAMP(3); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(0); } while (0)
+      auto after = [&](int u) { return tile_at(st, u); };   // the tile in slot u of this stage (u >= FS_KT: of the next stage)
+#ifdef STEIN_ABL_C_NOVLOAD   // (ablation build: the matrix waves keep the first V fragments)
+      constexpr bool kLoadV = false;
 #else
-#define BWAIT() do {} while (0)
+      constexpr bool kLoadV = true;
 #endif
 #pragma unroll
       for (int u = 0; u < FS_KT; u += 2) {
-        if (tile + u >= ntile) break;
-        BWAIT();
-        if (tile + u + 1 < ntile) load_b(tile + u + 1, bY);
+        if (after(u) >= ntile) break;
+        const bool n1 = after(u + 1) < ntile;
+        if (kLoadV && n1) load_b(after(u + 1), bY);
+        STAMP(3);
+        wait_b(kLoadV && n1, bX);
+        STAMP(0);   // diagnostic builds: waiting for this tile's V fragments
         mma_tile(As + u * FS_KTB, bX);
-        if (tile + u + 1 < ntile) {
-          BWAIT();
-          if (tile + u + 2 < ntile) load_b(tile + u + 2, bX);
+        if (n1) {
+          const bool n2 = after(u + 2) < ntile;
+          if (kLoadV && n2) load_b(after(u + 2), bX);
+          STAMP(3);
+          wait_b(kLoadV && n2, bY);
+          STAMP(0);
           mma_tile(As + (u + 1) * FS_KTB, bY);
         }
       }
@@ -671,6 +843,12 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       STAMP(4);   // consumer: barrier
     }
 #ifdef STEIN_STAMPS
+    if (t == 256) {
+      const u64 clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      atomicAdd(&g_clock[0], clk1 - clk0);
+      atomicAdd(&g_clock[1], rt1 - rt0);
+    }
     if (t == 256)
       for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
     if (t == 512) {   // the second matrix wave of the same SIMD

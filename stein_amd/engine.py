@@ -63,8 +63,8 @@ class HipStages:
 
     name = "hip"
 
-    def workspace_layout(self, n_local, n, d, flags=0):
-        return _lib.workspace_layout(n_local, n, d, _lib.F32, flags)
+    def workspace_layout(self, n_local, n, d, flags=0, dtype=_lib.F32):
+        return _lib.workspace_layout(n_local, n, d, dtype, flags)
 
     def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws, flags=0):
         _lib.call_on(T.device, "stein_svgd_phi", _ptr(T), _ptr(G), n, d, 0, n, _dt(T), _ptr(phi), _ptr(h2), _ptr(sqnorm),
@@ -181,7 +181,8 @@ class SvgdEngine:
         self.n_local = self.n // self.world
         self.row0 = self.rank * self.n_local
 
-        total, offs, extra = self.stages.workspace_layout(self.n_local, self.n, self.d, self.flags)
+        total, offs, extra = self.stages.workspace_layout(self.n_local, self.n, self.d, self.flags,
+                                                          _lib.BF16 if dtype == torch.bfloat16 else _lib.F32)
         self.ws_bytes, self._offs = total, offs
         self.ld_dist, self.split = extra[_lib.WSX_LD_DIST], extra[_lib.WSX_SPLIT]
         dev = self.device
