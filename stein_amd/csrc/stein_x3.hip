@@ -744,11 +744,24 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     const u16* __restrict__ vb = reinterpret_cast<const u16*>(
         ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)((unsigned long long)vb_wave >> 32)) << 32) |
         (unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(unsigned long long)vb_wave));
+#ifdef STEIN_MFMA32   // (experiment build: the matrix waves on the 32x32x16 shape)
+    constexpr bool M32 = true;
+#else
+    constexpr bool M32 = false;
+#endif
     u32 boff[2][3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)   // 16x16x32: j = 16-column block; 32x32x16: j = k step (lane: column lane & 31, chunk 2 j + (lane >> 5))
 #pragma unroll
-      for (int s = 0; s < 3; ++s) boff[j][s] = (u32)(lane * 8 + s * XTILE_E + j * 512) * 2u;
+      for (int s = 0; s < 3; ++s)
+        boff[j][s] = M32 ? (u32)(((((lane & 31) >> 4) * 4 + 2 * j + (lane >> 5)) * 16 + (lane & 15)) * 8 + s * XTILE_E) * 2u
+                         : (u32)(lane * 8 + s * XTILE_E + j * 512) * 2u;
+    const int aoff32[2] = {(lane & 31) * XROW + pswz(lane & 31, 0 + (lane >> 5)), (lane & 31) * XROW + pswz(lane & 31, 2 + (lane >> 5))};
+    f32x16 acc32[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
     const int aoff = l15 * XROW + pswz(l15, lq);   // A fragment of 16-row block ib, plane s: + ib * 1024 + s * XPLANE
     f32x4 acc[8][2];
 #pragma unroll
@@ -784,6 +797,23 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #endif
     };
     auto mma_tile = [&](const unsigned char* As, const u32x4 (&b)[2][3]) {
+      if constexpr (M32) {   // 4 row blocks of 32 x 2 k steps: fragments read one (block, step) ahead of their MFMAs
+        u32x4 a[2][3];
+        auto rd32 = [&](int q, u32x4 (&f)[3]) {   // q = 2 * row block + k step
+#pragma unroll
+          for (int s = 0; s < NP; ++s)
+            f[s] = *reinterpret_cast<const u32x4*>(As + aoff32[q & 1] + (q >> 1) * 32 * XROW + s * XPLANE);
+        };
+        rd32(0, a[0]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (q + 1 < 8) rd32(q + 1, a[(q + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          acc32[q >> 1] = x3_products<NP>(a[q & 1], b[q & 1], acc32[q >> 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
       u32x4 a[2][3];
       read_a(As, 0, a[0]);
 #pragma unroll
@@ -859,6 +889,20 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     float* __restrict__ Oz = (g < cblocks ? OG : OT) + (size_t)z * n_local * d;
     const int cbase = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + l15;
     const float* __restrict__ osc = sc + (g < cblocks ? 2 : 3) * dc;   // out-scales of this wave's matrix
+    if constexpr (M32) {
+      const int col = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + (lane & 31);
+      if (col < d) {
+        const float os = osc[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = i0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (row < n_local) Oz[(size_t)row * d + col] = acc32[i][e] * os;
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = cbase + j * 16;

@@ -115,3 +115,14 @@ def test_library_reads_no_environment():
     assert "getenv" not in out
     for src in ("steinhip.hip", "stein_x3.hip", "stein_small.hip", "stein_score.hip", "stein_common.h"):
         assert "getenv" not in open(os.path.join(ROOT, "stein_amd", "csrc", src)).read()
+
+
+def test_build_digest_does_not_depend_on_where_the_tree_lives(monkeypatch):
+    """The GPU box unpacks the snapshot under another absolute path; a digest that changed with it would rebuild the
+    library there in every process (and bench.py's stdout must stay one JSON line: build chatter goes to stderr)."""
+    import __graft_entry__ as ge
+    a = ge._digest(ge.SRCS + ge.HDRS, "lib")
+    monkeypatch.setattr(ge, "HIPCC_FLAGS", [f if not f.startswith("-I") else "-I/some/other/place/include" for f in ge.HIPCC_FLAGS])
+    assert ge._digest(ge.SRCS + ge.HDRS, "lib") == a
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert 'print("[build]", " ".join(cmd), flush=True)' not in src
