@@ -331,7 +331,7 @@ def main():
         "config": {"workload": wl["name"], "n": n, "d": d, "rows_per_rank": nl,
                    "optimizer": "adagrad lr=1e-3 alpha=0.9",
                    "parallelism": "rows sharded x%d, all-gather(theta,G) + median (3 histogram all-reduces, or one window-table "
-                                  "all-reduce when the local block has >= 2^27 entries) + 1 scalar all-reduce" % world
+                                  "all-reduce when the local block has >= 2^24 entries) + 1 scalar all-reduce" % world
                    if world > 1 else "single GPU"},
         "element_updates_per_s": value * d,
         "pair_interactions_per_s": value * n,

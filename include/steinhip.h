@@ -52,8 +52,10 @@ enum {
   STEIN_FLAG_TIMING = 4, /* stein_svgd_phi only: record a HIP event at every stage boundary (see stein_timing_reserve) */
   STEIN_FLAG_TILED = 8,  /* stein_svgd_phi only: never take the one-kernel path for n <= 160 (stein_small.hip); the
                             tiled kernels then also leave D, the histograms and the planes in the workspace */
-  STEIN_FLAG_NO_WINDOW = 16 /* stein_svgd_phi only: never grant the speculative median window, i.e. run the radix-select
-                               passes over D on every call (same result; what a window miss costs, for measurements) */
+  STEIN_FLAG_NO_WINDOW = 16, /* stein_svgd_phi only: never grant the speculative median window, i.e. run the radix-select
+                                passes over D on every call (same result; what a window miss costs, for measurements) */
+  STEIN_FLAG_RANK_WINDOW = 32 /* stein_rank_* only: this step uses the cross-rank speculative window (tally / pick) instead
+                                 of the radix-select histograms */
 };
 /* flags for the staged distance / histogram calls */
 enum {
@@ -208,6 +210,36 @@ int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t r
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
                           void* workspace, size_t ws_bytes, int flags /* same STEIN_FLAG_* as the partial */,
                           void* stream);
+
+/* ---- rank-step segments (row-sharded runs) ------------------------------------------------------------------------
+ * What one rank does between two collectives, one call each: the staged calls above chained on `stream`, so that the
+ * host layer issues per step only  all-gather(theta), all-gather(score) | stein_rank_begin | all-reduce | stein_rank_pick
+ * (window form) or stein_rank_radix x3 with an all-reduce before each (radix form) | stein_rank_finish |
+ * all-reduce(|phi|^2).  `workspace` is sized by stein_workspace_bytes(n_local, n, d, dtype, flags | STEIN_FLAG_TILED);
+ * flags: STEIN_FLAG_X3 and, for the window form, STEIN_FLAG_RANK_WINDOW.  They replace, for rank p's rows, the same
+ * reference lines as stein_svgd_phi.
+ *   stein_rank_begin   row norms, theta's operand planes, median set-up, the [n_local, n] distance block (level-0
+ *                      histogram or window counting in its epilogue) and, window form, the tally.  Then all-reduce(sum)
+ *                      the window table (65544 uint64 at 2^21 uint64 into the SPEC section) or histogram level 0.
+ *   stein_rank_pick    window form: both median targets from the summed table -> h2 / median; copies the 28 bytes of
+ *                      window state from `hit` to `skip_l0` (uint32 [0] = hit, [6] = skip_l0) to flags_host -- page-locked
+ *                      host memory -- on the stream: wait for it (an event) and, if hit == 0, run the radix form:
+ *                      stein_rank_radix(0, need_pass = !skip_l0) then all-reduce level 0, stein_rank_radix(0, 0) ...
+ *   stein_rank_radix   need_pass = 1: add the local block's histogram of `level`.  need_pass = 0 (hist[level] has been
+ *                      summed over the ranks): resolve `level` and, below the last level, take the local histogram of
+ *                      level + 1 (all-reduce it, call again).  After level 2: h2 / median are final.
+ *   stein_rank_finish  window form: predictor update; then the contraction on the local rows -> phi_local, the local part
+ *                      of |phi|^2 (all-reduce it), optional dK.  The score's operand planes must have been built
+ *                      (stein_x3_prepare(NULL, score_all, ...), any time after the score rows have arrived). */
+int stein_rank_begin(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                     void* workspace, size_t ws_bytes, int flags, void* stream);
+int stein_rank_pick(int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype, void* workspace, size_t ws_bytes,
+                    int flags, float* h2_out, float* median_out, void* flags_host, void* stream);
+int stein_rank_radix(int level, int need_pass, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                     void* workspace, size_t ws_bytes, int flags, float* h2_out, float* median_out, void* stream);
+int stein_rank_finish(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
+                      int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
+                      void* workspace, size_t ws_bytes, int flags, void* stream);
 
 /* Stage timing of the fused call (profiling aid; the events belong to the calling thread, like the last-error string:
  * reserve, call and read from one thread).  stein_timing_reserve(calls)

@@ -23,6 +23,7 @@ FLAG_X3 = 1
 FLAG_TIMING = 4
 FLAG_TILED = 8
 FLAG_NO_WINDOW = 16
+FLAG_RANK_WINDOW = 32
 GLM_LINEAR, GLM_LOGISTIC = 0, 1
 SPEC_TABLE_WORDS = 65544          # uint64 words of the rank-summed window table ...
 SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC section (slots + entry buffer)
@@ -45,6 +46,10 @@ _SIGNATURES = {
     "stein_spec_update": [_vp, _vp],
     "stein_score_glm": [_vp, _i64, _i64, _int, _i64, _i64, _i64, _vp, _vp, _i64, _dbl, _dbl, _dbl, _vp, _vp],
     "stein_score_bnn": [_vp, _i64, _i64, _i64, _i64, _c.POINTER(_i64), _vp, _vp, _i64, _dbl, _dbl, _dbl, _vp, _vp],
+    "stein_rank_begin": [_vp, _i64, _i64, _i64, _i64, _int, _vp, _sz, _int, _vp],
+    "stein_rank_pick": [_i64, _i64, _i64, _i64, _int, _vp, _sz, _int, _vp, _vp, _vp, _vp],
+    "stein_rank_radix": [_int, _int, _i64, _i64, _i64, _i64, _int, _vp, _sz, _int, _vp, _vp, _vp],
+    "stein_rank_finish": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_timing_reserve": [_int],
     "stein_timing_read": [_c.POINTER(_c.c_float), _int, _c.POINTER(_int)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],

@@ -1070,7 +1070,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
-  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -1446,6 +1446,98 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
   if (rc) return rc;
   return stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
                                ws_bytes, x3_planes ? STEIN_FLAG_X3 : 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank-step segments: what one rank of a row-sharded run does between two collectives, as ONE call each (the staged calls
+// above, chained on the stream).  The host layer issues: all-gather(theta), all-gather(score) | stein_rank_begin |
+// all-reduce(window table or level-0 histogram) | stein_rank_pick or stein_rank_radix x3 (an all-reduce before each) |
+// stein_rank_finish | all-reduce(|phi|^2).
+// ------------------------------------------------------------------------------------------------
+struct RankViews {
+  SteinLayout L;
+  float* r; float* D; u64* hist; char* sel; u64* spec_buf; char* planes;
+};
+static int rank_views(int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype, void* workspace, size_t ws_bytes,
+                      int flags, RankViews* v) {
+  if (!workspace) return fail(STEIN_E_BADARG, "NULL pointer");
+  if (row0 < 0 || n_local < 1 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TILED | STEIN_FLAG_RANK_WINDOW)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  int rc = stein_make_layout(n_local, n, d, dtype, (flags & (STEIN_FLAG_X3 | STEIN_FLAG_TILED)) | STEIN_FLAG_TILED, &v->L);
+  if (rc) return rc;
+  if (dtype == STEIN_BF16 && !(flags & STEIN_FLAG_X3)) return fail(STEIN_E_UNSUPPORTED, "bf16 inputs need STEIN_FLAG_X3");
+  if (ws_bytes < v->L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, v->L.total);
+  char* ws = (char*)workspace;
+  v->r = (float*)(ws + v->L.off[STEIN_WS_ROWNORM]);
+  v->D = (float*)(ws + v->L.off[STEIN_WS_DIST]);
+  v->hist = (u64*)(ws + v->L.off[STEIN_WS_HIST]);
+  v->sel = ws + v->L.off[STEIN_WS_SELECT];
+  v->spec_buf = (u64*)(ws + v->L.off[STEIN_WS_SPEC]);
+  v->planes = (flags & STEIN_FLAG_X3) ? ws + v->L.off[STEIN_WS_PLANES] : nullptr;
+  return STEIN_OK;
+}
+
+extern "C" int stein_rank_begin(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                                void* workspace, size_t ws_bytes, int flags, void* stream) {
+  if (!theta_all) return fail(STEIN_E_BADARG, "NULL pointer");
+  RankViews v;
+  int rc = rank_views(n, d, row0, n_local, dtype, workspace, ws_bytes, flags, &v);
+  if (rc) return rc;
+  const bool window = (flags & STEIN_FLAG_RANK_WINDOW) != 0;
+  if ((rc = stein_rownorms(theta_all, n, d, dtype, v.r, stream))) return rc;
+  if (v.planes && (rc = stein_x3_split(theta_all, nullptr, dtype, n, d, v.L, v.planes, (hipStream_t)stream))) return rc;
+  if (window) rc = stein_spec_begin(v.hist, v.sel, v.spec_buf, n * n, stream);
+  else rc = stein_median_begin(v.hist, v.sel, n * n, stream);
+  if (rc) return rc;
+  if ((rc = distance_block_impl(theta_all, v.r, n, d, row0, n_local, dtype, v.D, v.L.ld_dist, v.hist, v.planes, 0, stream,
+                                window ? spec_of(v.sel) : nullptr, window ? v.spec_buf : nullptr)))
+    return rc;
+  if (window) rc = stein_spec_tally(v.sel, v.spec_buf, stream);
+  return rc;
+}
+
+extern "C" int stein_rank_pick(int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype, void* workspace,
+                               size_t ws_bytes, int flags, float* h2_out, float* median_out, void* flags_host,
+                               void* stream) {
+  if (!h2_out || !flags_host) return fail(STEIN_E_BADARG, "NULL pointer");
+  RankViews v;
+  int rc = rank_views(n, d, row0, n_local, dtype, workspace, ws_bytes, flags, &v);
+  if (rc) return rc;
+  if ((rc = stein_spec_pick(v.sel, v.spec_buf, n, h2_out, median_out, stream))) return rc;
+  // `hit` (SpecState + 28) .. `skip_l0` (+ 52): 28 bytes, to page-locked host memory the caller polls behind an event
+  HIP_TRY(hipMemcpyAsync(flags_host, v.sel + sizeof(SelState) + 28, 28, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return STEIN_OK;
+}
+
+extern "C" int stein_rank_radix(int level, int need_pass, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
+                                void* workspace, size_t ws_bytes, int flags, float* h2_out, float* median_out,
+                                void* stream) {
+  // need_pass: first take this level's histogram of the local block (level 0 after a window miss that skipped it);
+  // then (the caller has summed hist[level] over the ranks unless need_pass) ... see include/steinhip.h
+  RankViews v;
+  int rc = rank_views(n, d, row0, n_local, dtype, workspace, ws_bytes, flags, &v);
+  if (rc) return rc;
+  if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
+  if (need_pass) return hist_pass_impl(v.D, v.L.ld_dist, n_local, n, level, v.sel, v.hist, 0, stream, nullptr);
+  if ((rc = resolve_impl(v.hist, level, n, v.sel, h2_out, median_out, stream, nullptr))) return rc;
+  if (level + 1 < STEIN_HIST_LEVELS)
+    rc = hist_pass_impl(v.D, v.L.ld_dist, n_local, n, level + 1, v.sel, v.hist, 0, stream, nullptr);
+  return rc;
+}
+
+extern "C" int stein_rank_finish(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0,
+                                 int64_t n_local, int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
+                                 float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
+  if (!theta_all || !score_all || !h2_dev || !phi_local || !sqnorm_out) return fail(STEIN_E_BADARG, "NULL pointer");
+  RankViews v;
+  int rc = rank_views(n, d, row0, n_local, dtype, workspace, ws_bytes, flags, &v);
+  if (rc) return rc;
+  if ((flags & STEIN_FLAG_RANK_WINDOW) && (rc = stein_spec_update(v.sel, stream))) return rc;
+  if ((rc = stein_contract_partial(v.D, v.L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, v.planes,
+                                   workspace, ws_bytes, stream)))
+    return rc;
+  return stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
+                               ws_bytes, v.planes ? STEIN_FLAG_X3 : 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -120,6 +120,22 @@ class HipStages:
         _lib.call_on(T.device, "stein_contract_finish", _ptr(T), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi),
                   _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
+    # -- rank-step segments: everything one rank does between two collectives, one C call each (include/steinhip.h) --
+    def rank_begin(self, T, n, d, row0, n_local, ws, flags):
+        _lib.call_on(T.device, "stein_rank_begin", _ptr(T), n, d, row0, n_local, _dt(T), _ptr(ws), ws.numel(), flags, _stream(T))
+
+    def rank_pick(self, T, n, d, row0, n_local, ws, flags, h2, median, flags_host):
+        _lib.call_on(T.device, "stein_rank_pick", n, d, row0, n_local, _dt(T), _ptr(ws), ws.numel(), flags, _ptr(h2), _ptr(median),
+                     ctypes.c_void_p(flags_host.data_ptr()), _stream(T))
+
+    def rank_radix(self, T, level, need_pass, n, d, row0, n_local, ws, flags, h2, median):
+        _lib.call_on(T.device, "stein_rank_radix", level, 1 if need_pass else 0, n, d, row0, n_local, _dt(T), _ptr(ws), ws.numel(),
+                     flags, _ptr(h2), _ptr(median), _stream(T))
+
+    def rank_finish(self, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, flags):
+        _lib.call_on(T.device, "stein_rank_finish", _ptr(T), _ptr(G), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi), _ptr(sqnorm),
+                     _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
+
     def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
         self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws, planes)
         self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, _lib.FLAG_X3 if planes is not None else 0)
@@ -156,10 +172,10 @@ class SvgdEngine:
         # same results -- bench.py times the miss path this way)
         self.flags = ((_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED) |
                       (0 if window else _lib.FLAG_NO_WINDOW))
-        # several ranks: use the speculative median window (one 512 KB all-reduce and a hit-flag read-back per step
-        # instead of two passes over the local distance block) when the block is large enough for that to pay
-        # (>= 2^27 entries: the two passes then cost more than the table all-reduce plus the read-back stall);
-        # STEIN_DIST_WINDOW=0/1 forces it
+        # several ranks: use the speculative median window (ONE 512 KB all-reduce and a hit-flag read-back per step
+        # instead of three histogram all-reduces and two passes over the local distance block) when the block is large
+        # enough for that to pay (>= 2^24 entries; every collective costs ~30 us of host time from Python, and the
+        # read-back no longer leaves a bubble on the stream: _sharded_step); STEIN_DIST_WINDOW=0/1 forces it
         self.dist_window = False
         self.window_hit = None
         self.device = torch.device(device)
@@ -181,6 +197,8 @@ class SvgdEngine:
         self.n_local = self.n // self.world
         self.row0 = self.rank * self.n_local
 
+        if self.sharded:
+            self.flags |= _lib.FLAG_TILED        # a rank never takes the one-kernel path; its workspace has every section
         total, offs, extra = self.stages.workspace_layout(self.n_local, self.n, self.d, self.flags,
                                                           _lib.BF16 if dtype == torch.bfloat16 else _lib.F32)
         self.ws_bytes, self._offs = total, offs
@@ -197,10 +215,12 @@ class SvgdEngine:
         self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
         if self.sharded and hasattr(self.stages, "spec_begin"):
             env = os.environ.get("STEIN_DIST_WINDOW", "")
-            self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 27))
+            self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 24))
         if self.sharded:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
+        self._flags_host = None      # page-locked landing place of the window's hit flag (HIP stages, window form)
+        self._flags_event = None
 
     # views into the workspace -------------------------------------------------------------
     def _section(self, sec, nbytes, dtype):
@@ -293,6 +313,53 @@ class SvgdEngine:
             self._radix_levels(0, need_level0_pass=not skip_l0)
         st.spec_update(sel)
 
+    def _sharded_step(self, theta_local, score_local, dK_out):
+        """The multi-rank step on the HIP stages: one C call per segment between collectives (stein_rank_*), nothing
+        else from the host but the collectives themselves.  In the window form the hit flag lands in page-locked memory
+        behind an event; the host waits for it while the GPU already builds the score's operand planes, so the read-back
+        leaves no bubble on the stream."""
+        import torch.distributed as dist
+        st, n, d, nl, row0, ws = self.stages, self.n, self.d, self.n_local, self.row0, self.ws
+        flags = (self.flags & _lib.FLAG_X3) | (_lib.FLAG_RANK_WINDOW if self.dist_window else 0)
+        T_all, G_all, planes = self.T_all, self.G_all, self.planes
+        # theta first (collectives of one group run in issue order); the score rows are not needed before the
+        # contraction, so their all-gather is asynchronous and runs beside the distance pass
+        dist.all_gather_into_tensor(T_all, theta_local, group=self.group)
+        gather_g = dist.all_gather_into_tensor(G_all, score_local, group=self.group, async_op=True)
+        st.rank_begin(T_all, n, d, row0, nl, ws, flags)
+
+        def score_planes():
+            gather_g.wait()            # the launching stream waits for the gathered score rows (the host does not)
+            if planes is not None:
+                st.x3_prepare(None, G_all, n, d, planes)
+
+        def radix(need_level0_pass):
+            if need_level0_pass:
+                st.rank_radix(T_all, 0, True, n, d, row0, nl, ws, flags, self.h2, self.median)
+            for level in range(_lib.HIST_LEVELS):
+                dist.all_reduce(self.hist[level], op=dist.ReduceOp.SUM, group=self.group)
+                st.rank_radix(T_all, level, False, n, d, row0, nl, ws, flags, self.h2, self.median)
+
+        if self.dist_window:
+            if self._flags_host is None:
+                self._flags_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+                self._flags_event = torch.cuda.Event()
+            dist.all_reduce(self.spec_table, op=dist.ReduceOp.SUM, group=self.group)
+            st.rank_pick(T_all, n, d, row0, nl, ws, flags, self.h2, self.median, self._flags_host)
+            self._flags_event.record(torch.cuda.current_stream(self.device))
+            score_planes()                       # GPU work that does not depend on the flag: covers the host's wake-up
+            self._flags_event.synchronize()
+            hit, skip_l0 = bool(self._flags_host[0]), bool(self._flags_host[6])
+            self.window_hit = hit
+            if not hit:
+                radix(not skip_l0)
+        else:
+            radix(False)
+            score_planes()
+        st.rank_finish(T_all, G_all, n, d, row0, nl, self.h2, self.phi, self.sqnorm, dK_out, ws, flags)
+        dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+        return self.phi
+
     def compute_phi(self, theta_local, score_local, K_out=None, dK_out=None, mark=None, timing=False):
         """theta_local, score_local: [n_local, d] float32 contiguous device tensors (this rank's rows).
 
@@ -315,6 +382,8 @@ class SvgdEngine:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
                         self.flags | (_lib.FLAG_TIMING if timing else 0))
             return self.phi
+        if self.sharded and mark is None and K_out is None and hasattr(st, "rank_begin"):
+            return self._sharded_step(theta_local, score_local, dK_out)
         if mark is None:
             def mark(label):
                 return None
