@@ -128,10 +128,11 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     feed = (lambda: theta.to(torch.bfloat16)) if bf16 else (lambda: theta)
     clock = StageClock(torch)
 
-    # Single rank: the fused C call (what SteinSampler.update_particles runs), with the library recording HIP events
-    # at its stage boundaries on the launching stream (STEIN_FLAG_TIMING).  Several ranks: the staged calls with a
-    # HIP event at every mark.
-    fused = world == 1
+    # The step is what SteinSampler.update_particles runs: the fused C call on a single rank, the rank-step segments with
+    # the collectives between them on several.  Either way the library records HIP events on the launching stream
+    # (STEIN_FLAG_TIMING): at every stage boundary of the fused call, around the contraction and the finish pass of a
+    # sharded step (the other stages of a sharded step are separated by collectives and are not split here).
+    fused = True
     apply_events = []
     if fused and clock_stages:
         _lib.timing_reserve(steps)
@@ -161,7 +162,7 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     if world > 1:
         dist.barrier(group=group)
     torch.cuda.synchronize(device)
-    has_window = fused and window and n > 160            # the one-kernel path (n <= 160) keeps no window state
+    has_window = world == 1 and window and n > 160       # the one-kernel path (n <= 160) keeps no window state
     stats0 = eng.window_stats() if has_window else (0, 0)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -178,7 +179,8 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     stats1 = eng.window_stats() if has_window else (0, 0)
     if fused and clock_stages:
         per_call = _lib.timing_read(steps)
-        stages = {k: round(sum(c[k] for c in per_call) / max(1, len(per_call)), 4) for k in _lib.T_STAGES}
+        stages = {k: round(sum(c[k] for c in per_call) / max(1, len(per_call)), 4) for k in _lib.T_STAGES
+                  if world == 1 or k in ("contract", "finish")}
         stages["apply"] = round(sum(a.elapsed_time(b) for a, b in apply_events) / max(1, len(apply_events)), 4)
     else:
         stages = clock.summary() if clock_stages else {}

@@ -1454,6 +1454,9 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
 // all-reduce(window table or level-0 histogram) | stein_rank_pick or stein_rank_radix x3 (an all-reduce before each) |
 // stein_rank_finish | all-reduce(|phi|^2).
 // ------------------------------------------------------------------------------------------------
+static thread_local std::vector<hipEvent_t> g_tevents;   // (STEIN_T_NSTAGES + 1) events per reserved call
+static thread_local int g_tcalls_reserved = 0, g_tcalls_used = 0;
+
 struct RankViews {
   SteinLayout L;
   float* r; float* D; u64* hist; char* sel; u64* spec_buf; char* planes;
@@ -1462,7 +1465,7 @@ static int rank_views(int64_t n, int64_t d, int64_t row0, int64_t n_local, int d
                       int flags, RankViews* v) {
   if (!workspace) return fail(STEIN_E_BADARG, "NULL pointer");
   if (row0 < 0 || n_local < 1 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
-  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TILED | STEIN_FLAG_RANK_WINDOW)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TILED | STEIN_FLAG_RANK_WINDOW | STEIN_FLAG_TIMING)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   int rc = stein_make_layout(n_local, n, d, dtype, (flags & (STEIN_FLAG_X3 | STEIN_FLAG_TILED)) | STEIN_FLAG_TILED, &v->L);
   if (rc) return rc;
   if (dtype == STEIN_BF16 && !(flags & STEIN_FLAG_X3)) return fail(STEIN_E_UNSUPPORTED, "bf16 inputs need STEIN_FLAG_X3");
@@ -1533,18 +1536,26 @@ extern "C" int stein_rank_finish(const void* theta_all, const void* score_all, i
   int rc = rank_views(n, d, row0, n_local, dtype, workspace, ws_bytes, flags, &v);
   if (rc) return rc;
   if ((flags & STEIN_FLAG_RANK_WINDOW) && (rc = stein_spec_update(v.sel, stream))) return rc;
+  // STEIN_FLAG_TIMING: the contraction and the finish pass are bracketed by HIP events on the stream (the earlier
+  // stages of the slot read as zero length); read them back with stein_timing_read
+  hipEvent_t* tev = nullptr;
+  if ((flags & STEIN_FLAG_TIMING) && g_tcalls_used < g_tcalls_reserved)
+    tev = &g_tevents[(size_t)(g_tcalls_used++) * (STEIN_T_NSTAGES + 1)];
+  if (tev)
+    for (int k = 0; k <= STEIN_T_CONTRACT; ++k) HIP_TRY(hipEventRecord(tev[k], (hipStream_t)stream));
   if ((rc = stein_contract_partial(v.D, v.L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, v.planes,
                                    workspace, ws_bytes, stream)))
     return rc;
-  return stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
-                               ws_bytes, v.planes ? STEIN_FLAG_X3 : 0, stream);
+  if (tev) HIP_TRY(hipEventRecord(tev[STEIN_T_FINISH], (hipStream_t)stream));
+  rc = stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
+                             ws_bytes, v.planes ? STEIN_FLAG_X3 : 0, stream);
+  if (tev && !rc) HIP_TRY(hipEventRecord(tev[STEIN_T_NSTAGES], (hipStream_t)stream));
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage timing of the fused call (profiling aid; per calling thread, like the last-error string)
 // ------------------------------------------------------------------------------------------------
-static thread_local std::vector<hipEvent_t> g_tevents;   // (STEIN_T_NSTAGES + 1) events per reserved call
-static thread_local int g_tcalls_reserved = 0, g_tcalls_used = 0;
 
 extern "C" int stein_timing_reserve(int calls) {
   if (calls < 0) return fail(STEIN_E_BADARG, "calls < 0");

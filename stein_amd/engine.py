@@ -313,7 +313,7 @@ class SvgdEngine:
             self._radix_levels(0, need_level0_pass=not skip_l0)
         st.spec_update(sel)
 
-    def _sharded_step(self, theta_local, score_local, dK_out):
+    def _sharded_step(self, theta_local, score_local, dK_out, timing=False):
         """The multi-rank step on the HIP stages: one C call per segment between collectives (stein_rank_*), nothing
         else from the host but the collectives themselves.  In the window form the hit flag lands in page-locked memory
         behind an event; the host waits for it while the GPU already builds the score's operand planes, so the read-back
@@ -356,7 +356,8 @@ class SvgdEngine:
         else:
             radix(False)
             score_planes()
-        st.rank_finish(T_all, G_all, n, d, row0, nl, self.h2, self.phi, self.sqnorm, dK_out, ws, flags)
+        st.rank_finish(T_all, G_all, n, d, row0, nl, self.h2, self.phi, self.sqnorm, dK_out, ws,
+                       flags | (_lib.FLAG_TIMING if timing else 0))
         dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
         return self.phi
 
@@ -370,8 +371,9 @@ class SvgdEngine:
         HIP events there to time individual kernels).  Passing it selects the staged calls: the same kernels
         as the fused call except that the median always takes the radix-select passes (the speculative
         window of the fused call needs state that persists inside one workspace, see stein_common.h).
-        timing: single rank only -- keep the fused call and let the library record HIP events at its stage
-        boundaries (_lib.timing_reserve / _lib.timing_read).
+        timing: let the library record HIP events on the stream at its stage boundaries (_lib.timing_reserve /
+        _lib.timing_read): every stage of the fused call on a single rank, the contraction and the finish pass in a
+        sharded step.
         """
         st, n, d, nl = self.stages, self.n, self.d, self.n_local
         for name, t in (("theta", theta_local), ("score", score_local)):
@@ -383,7 +385,7 @@ class SvgdEngine:
                         self.flags | (_lib.FLAG_TIMING if timing else 0))
             return self.phi
         if self.sharded and mark is None and K_out is None and hasattr(st, "rank_begin"):
-            return self._sharded_step(theta_local, score_local, dK_out)
+            return self._sharded_step(theta_local, score_local, dK_out, timing)
         if mark is None:
             def mark(label):
                 return None
