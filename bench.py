@@ -120,8 +120,25 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     row0 = rank * n_local
     T64, G64, theta, G = make_inputs(n, d, row0, n_local, device, torch)
     bf16 = bool(wl.get("bf16"))      # BASELINE config 2: the kernels see bf16 theta / score; theta's master copy stays fp32
-    eng = SvgdEngine(n, d, device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32, x3=x3,
-                     window=window)
+    ekw = dict(device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32, x3=x3, window=window)
+    comm_note = None
+    if world > 1:
+        # the library's own RCCL communicator (the step is one C call); every rank must take the same path, so the
+        # ranks agree on whether all of them got a communicator and otherwise all use torch.distributed's collectives
+        try:
+            eng = SvgdEngine(n, d, comm="native", **ekw)
+            ok, why = 1, ""
+        except Exception as exc:      # noqa: BLE001 -- reported in the JSON line, never silent
+            eng, ok, why = None, 0, "%s: %s" % (type(exc).__name__, exc)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            if eng is not None:
+                eng.close()
+            eng = SvgdEngine(n, d, comm="torch", **ekw)
+            comm_note = "library communicator unavailable on some rank (%s): torch.distributed collectives" % (why or "other rank")
+    else:
+        eng = SvgdEngine(n, d, **ekw)
     gd = AdagradGradientDescent(learning_rate=1e-3, alpha=0.9)
     if bf16:
         G = G.to(torch.bfloat16)
@@ -196,7 +213,21 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     else:
         T_all, G_all = cur.float(), G.float()
     relerr, nrows = parity_sample(torch, T_all, G_all, phi, row0, float(eng.h2.item()))
-    return dict(n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
+    crosscheck = None
+    if world > 1 and eng.comm == "native":
+        # the same step with torch.distributed issuing the collectives between the rank segments: same kernels, same
+        # data, so phi and the bandwidth must come out bit-identical (|phi|^2 to the order of its fp64 rank sum)
+        phi_native, h2_native, sq_native = phi.clone(), float(eng.h2.item()), float(eng.sqnorm.item())
+        other = SvgdEngine(n, d, comm="torch", **ekw)
+        other.ws[other._offs[_lib.WS_SELECT]:other._offs[_lib.WS_SELECT] + _lib.SELECT_BYTES].copy_(
+            eng.ws[eng._offs[_lib.WS_SELECT]:eng._offs[_lib.WS_SELECT] + _lib.SELECT_BYTES])
+        phi_torch = other.compute_phi(cur, G)
+        torch.cuda.synchronize(device)
+        crosscheck = dict(phi_max_abs_diff=float((phi_torch - phi_native).abs().max().item()),
+                          h2_equal=bool(float(other.h2.item()) == h2_native),
+                          sqnorm_rel_diff=abs(float(other.sqnorm.item()) - sq_native) / max(sq_native, 1e-300))
+        del other
+    return dict(comm=eng.comm, comm_note=comm_note, comm_crosscheck=crosscheck, n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
                 ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3, parity_relerr=relerr, parity_rows=nrows,
                 window=dict(timed_steps=stats1[0] - stats0[0], hits=stats1[1] - stats0[1]) if has_window else None)
 
@@ -346,6 +377,10 @@ def main():
         "parity_sample_relerr": res["parity_relerr"],
         "parity_sample_rows": res["parity_rows"],
     }
+    if world > 1:
+        out["collectives"] = {"issued_by": {"native": "libsteinhip (own RCCL communicator, stein_rank_step: one C call per step)",
+                                            "torch": "torch.distributed (nccl = RCCL) between the rank segments"}[res["comm"]],
+                              "note": res["comm_note"], "crosscheck_vs_torch_collectives": res["comm_crosscheck"]}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, res["T64"], res["G64"], args.cpu_rows)
     del res

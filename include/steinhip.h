@@ -35,7 +35,7 @@ enum {
   STEIN_E_SHAPE = -2,
   STEIN_E_WORKSPACE = -3,
   STEIN_E_HIP = -4,
-  STEIN_E_RCCL = -5, /* reserved: collectives are issued by the host layer through torch.distributed */
+  STEIN_E_RCCL = -5, /* an RCCL call of the library's own communicator failed (stein_comm_*, stein_rank_step) */
   STEIN_E_UNSUPPORTED = -6
 };
 
@@ -240,6 +240,31 @@ int stein_rank_radix(int level, int need_pass, int64_t n, int64_t d, int64_t row
 int stein_rank_finish(const void* theta_all, const void* score_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
                       int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
                       void* workspace, size_t ws_bytes, int flags, void* stream);
+
+/* ---- the sharded step with the library's own RCCL communicator ("one communicator per process-rank") ----
+ * The reference has no counterpart (stein_sampler.py:11-14 "does not exploit parallelism"); per rank the step replaces
+ * the same reference lines as stein_svgd_phi.  RCCL is looked up at run time (the copy already loaded in the process,
+ * e.g. PyTorch-ROCm's, else librccl.so.1); without it these calls return STEIN_E_RCCL.
+ *   stein_comm_unique_id  one rank makes the 128-byte id; the host layer hands it to every rank (any channel).
+ *   stein_comm_init       collective over the nranks processes, on the CURRENT HIP device; blocks until all have joined.
+ *   stein_rank_step       one whole step for rank p's rows [p n / nranks, (p + 1) n / nranks), queued on `stream`:
+ *                         all-gather(theta rows, score rows) as one group -> stein_rank_begin -> all-reduce of the window
+ *                         table -> stein_rank_pick (window form, STEIN_FLAG_RANK_WINDOW; the call waits for the 4-byte hit
+ *                         flag and on a miss runs the radix form) or three histogram all-reduces with stein_rank_radix
+ *                         (radix form: nothing waits) -> stein_rank_finish -> all-reduce(|phi|^2).
+ *                         theta_all / score_all: [n, d] gather targets; h2_out, median_out, sqnorm_out: device scalars,
+ *                         identical on every rank afterwards; window_hit_out (may be NULL): 1 / 0, -1 in the radix form.
+ *                         flags: STEIN_FLAG_X3, STEIN_FLAG_RANK_WINDOW, STEIN_FLAG_TIMING; workspace sized by
+ *                         stein_workspace_bytes(n / nranks, n, d, dtype, flags | STEIN_FLAG_TILED). */
+#define STEIN_COMM_ID_BYTES 128
+int stein_comm_unique_id(void* id_out, size_t id_bytes);
+int stein_comm_init(const void* id, size_t id_bytes, int nranks, int rank, void** comm_out);
+int stein_comm_info(void* comm, int* nranks_out, int* rank_out);
+int stein_comm_destroy(void* comm);
+int stein_rank_step(void* comm, const void* theta_local, const void* score_local, void* theta_all, void* score_all,
+                    int64_t n, int64_t d, int dtype, float* phi_local, float* h2_out, float* median_out,
+                    double* sqnorm_out, float* dK_out, void* workspace, size_t ws_bytes, int flags,
+                    int* window_hit_out, void* stream);
 
 /* Stage timing of the fused call (profiling aid; the events belong to the calling thread, like the last-error string:
  * reserve, call and read from one thread).  stein_timing_reserve(calls)

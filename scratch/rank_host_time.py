@@ -11,14 +11,17 @@ from stein_amd.engine import SvgdEngine
 for n, d in ((2048, 256), (16384, 256)):
     T = torch.randn(n, d, device=dev); G = torch.randn(n, d, device=dev)
     for name, env, kw, ekw in (("fused (single rank)", "0", {}, {}),
-                               ("segments, radix form", "0", {}, dict(group=dist.group.WORLD, force_collectives=True)),
-                               ("segments, window form", "1", {}, dict(group=dist.group.WORLD, force_collectives=True)),
-                               ("staged calls, radix form (round 1)", "0", dict(mark=lambda s: None), dict(group=dist.group.WORLD, force_collectives=True))):
+                               ("stein_rank_step (library RCCL), radix", "0", {}, dict(group=dist.group.WORLD, force_collectives=True, comm="native")),
+                               ("stein_rank_step (library RCCL), window", "1", {}, dict(group=dist.group.WORLD, force_collectives=True, comm="native")),
+                               ("segments + torch collectives, radix", "0", {}, dict(group=dist.group.WORLD, force_collectives=True, comm="torch")),
+                               ("segments + torch collectives, window", "1", {}, dict(group=dist.group.WORLD, force_collectives=True, comm="torch")),
+                               ("staged calls, radix form (round 1)", "0", dict(mark=lambda s: None), dict(group=dist.group.WORLD, force_collectives=True, comm="torch"))):
         os.environ["STEIN_DIST_WINDOW"] = env
         eng = SvgdEngine(n, d, device=dev, small=False, **ekw)
         for _ in range(8): eng.compute_phi(T, G, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(50): eng.compute_phi(T, G, **kw)
         t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-        print("n=%d d=%d %-36s host issue %.1f us/step, wall %.1f us/step" % (n, d, name, (t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6), flush=True)
+        if hasattr(eng, "close"): eng.close()
+        print("n=%d d=%d %-40s host issue %.1f us/step, wall %.1f us/step" % (n, d, name, (t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6), flush=True)
 dist.destroy_process_group()

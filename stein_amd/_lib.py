@@ -30,6 +30,7 @@ SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC s
 SPEC_HIT_OFFSET, SPEC_SKIP_L0_OFFSET = 64 + 28, 64 + 52   # uint32 state words inside the SELECT section
 SPEC_NSTEPS_OFFSET, SPEC_NHITS_OFFSET = 64 + 56, 64 + 60   # medians recorded since the predictor started / window hits
 SELECT_BYTES = 192                                        # SelState + SpecState + FuseState
+COMM_ID_BYTES = 128                                       # STEIN_COMM_ID_BYTES
 T_STAGES = ("prepare", "distance", "median", "contract", "finish")   # STEIN_T_* of include/steinhip.h
 
 _c = ctypes
@@ -50,6 +51,12 @@ _SIGNATURES = {
     "stein_rank_pick": [_i64, _i64, _i64, _i64, _int, _vp, _sz, _int, _vp, _vp, _vp, _vp],
     "stein_rank_radix": [_int, _int, _i64, _i64, _i64, _i64, _int, _vp, _sz, _int, _vp, _vp, _vp],
     "stein_rank_finish": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
+    "stein_comm_unique_id": [_vp, _sz],
+    "stein_comm_init": [_vp, _sz, _int, _int, _c.POINTER(_vp)],
+    "stein_comm_info": [_vp, _c.POINTER(_int), _c.POINTER(_int)],
+    "stein_comm_destroy": [_vp],
+    "stein_rank_step": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int,
+                        _c.POINTER(_int), _vp],
     "stein_timing_reserve": [_int],
     "stein_timing_read": [_c.POINTER(_c.c_float), _int, _c.POINTER(_int)],
     "stein_svgd_phi": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],

@@ -2,8 +2,11 @@
 
 The arithmetic lives in libsteinhip.so; this module owns device buffers (PyTorch
 tensors), the caller-owned workspace, and -- when particles are sharded over
-ranks -- the collectives between the staged calls (torch.distributed, i.e. RCCL
-over xGMI on the GPU box):
+ranks -- the step's collectives.  On GPUs the library issues them itself on its
+own RCCL communicator, the whole step being ONE C call (stein_rank_step,
+comm="native"); the same protocol written out with torch.distributed
+collectives between the rank segments (comm="torch") serves every other backend
+(the gloo tests) and as the cross-check of the native path:
 
     all_gather(theta rows), all_gather(score rows)          once per step
     all_reduce(level histogram)  x3                          median select
@@ -136,6 +139,30 @@ class HipStages:
         _lib.call_on(T.device, "stein_rank_finish", _ptr(T), _ptr(G), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi), _ptr(sqnorm),
                      _ptr(dK), _ptr(ws), ws.numel(), flags, _stream(T))
 
+    # -- the library's own RCCL communicator: the whole sharded step as one call (include/steinhip.h) --
+    def comm_unique_id(self):
+        buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+        _lib.call("stein_comm_unique_id", buf, _lib.COMM_ID_BYTES)
+        return bytes(buf)
+
+    def comm_init(self, device, uid, nranks, rank):
+        """collective over the ranks; `device` becomes the communicator's device"""
+        out = ctypes.c_void_p(0)
+        buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
+        _lib.call_on(device, "stein_comm_init", buf, _lib.COMM_ID_BYTES, nranks, rank, ctypes.byref(out))
+        return out
+
+    def comm_destroy(self, comm):
+        _lib.call("stein_comm_destroy", comm)
+
+    def rank_step(self, comm, theta_local, score_local, T_all, G_all, n, d, phi, h2, median, sqnorm, dK, ws, flags):
+        """-> window hit (True / False; None in the radix form)"""
+        hit = ctypes.c_int(-1)
+        _lib.call_on(T_all.device, "stein_rank_step", comm, _ptr(theta_local), _ptr(score_local), _ptr(T_all), _ptr(G_all), n, d,
+                     _dt(T_all), _ptr(phi), _ptr(h2), _ptr(median), _ptr(sqnorm), _ptr(dK), _ptr(ws), ws.numel(), flags,
+                     ctypes.byref(hit), _stream(T_all))
+        return None if hit.value < 0 else bool(hit.value)
+
     def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
         self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws, planes)
         self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, _lib.FLAG_X3 if planes is not None else 0)
@@ -151,10 +178,14 @@ class SvgdEngine:
     group   : torch.distributed process group (None -> single rank).  n must divide evenly.
     stages  : backend implementing the staged calls; the product default is HipStages.
               (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
+    comm    : who issues the collectives of a sharded step.  "native": the library, on its own RCCL communicator, the
+              whole step one C call (stein_rank_step).  "torch": torch.distributed collectives between the rank
+              segments.  "auto" (default): native on GPUs with the HIP stages when the group's backend is nccl (RCCL),
+              torch otherwise.
     """
 
     def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True,
-                 window=True, force_collectives=False):
+                 window=True, force_collectives=False, comm="auto"):
         self.n, self.d = int(n), int(d)
         # dtype of the theta / score tensors handed to compute_phi: float32, or bfloat16 (BASELINE config 2: the
         # values are used as they are, K is rounded to bf16, one bf16 MFMA per product, fp32 accumulation)
@@ -221,6 +252,38 @@ class SvgdEngine:
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
         self._flags_host = None      # page-locked landing place of the window's hit flag (HIP stages, window form)
         self._flags_event = None
+        if comm not in ("auto", "native", "torch"):
+            raise ValueError("comm must be 'auto', 'native' or 'torch'")
+        self._comm = None
+        if self.sharded and comm != "torch":
+            import torch.distributed as dist
+            able = self.device.type == "cuda" and hasattr(self.stages, "rank_step") and "nccl" in str(dist.get_backend(group))
+            if comm == "native" and not able:
+                raise ValueError("comm='native' needs CUDA/HIP tensors, the HIP stages and an nccl (RCCL) process group")
+            if able:
+                self._comm = self._make_native_comm()
+        self.comm = "native" if self._comm is not None else ("torch" if self.sharded else None)
+
+    def _make_native_comm(self):
+        """group rank 0 makes the 128-byte RCCL id, the group broadcasts it, every rank joins (collective)."""
+        import torch.distributed as dist
+        uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(self.stages.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=dist.get_global_rank(self.group, 0), group=self.group)
+        return self.stages.comm_init(self.device, bytes(uid.cpu().numpy().tobytes()), self.world, self.rank)
+
+    def close(self):
+        """release the library's communicator (collective-free; safe to call twice)"""
+        comm, self._comm = self._comm, None
+        if comm is not None:
+            self.stages.comm_destroy(comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # views into the workspace -------------------------------------------------------------
     def _section(self, sec, nbytes, dtype):
@@ -383,6 +446,12 @@ class SvgdEngine:
         if not self.sharded and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
                         self.flags | (_lib.FLAG_TIMING if timing else 0))
+            return self.phi
+        if self.sharded and mark is None and K_out is None and self._comm is not None:
+            flags = ((self.flags & _lib.FLAG_X3) | (_lib.FLAG_RANK_WINDOW if self.dist_window else 0) |
+                     (_lib.FLAG_TIMING if timing else 0))
+            self.window_hit = st.rank_step(self._comm, theta_local, score_local, self.T_all, self.G_all, n, d, self.phi,
+                                           self.h2, self.median, self.sqnorm, dK_out, self.ws, flags)
             return self.phi
         if self.sharded and mark is None and K_out is None and hasattr(st, "rank_begin"):
             return self._sharded_step(theta_local, score_local, dK_out, timing)

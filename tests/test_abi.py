@@ -126,3 +126,22 @@ def test_build_digest_does_not_depend_on_where_the_tree_lives(monkeypatch):
     assert ge._digest(ge.SRCS + ge.HDRS, "lib") == a
     src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert 'print("[build]", " ".join(cmd), flush=True)' not in src
+
+
+def test_communicator_entry_points_check_their_arguments_without_rccl():
+    """stein_comm_* / stein_rank_step refuse bad handles and buffers before RCCL or the GPU is touched."""
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_ubyte * 64)()
+    assert lib.stein_comm_unique_id(buf, 64) == _lib.E_BADARG                 # the id is STEIN_COMM_ID_BYTES = 128 bytes
+    assert b"128" in lib.stein_last_error()
+    assert lib.stein_comm_unique_id(null, _lib.COMM_ID_BYTES) == _lib.E_BADARG
+    out = ctypes.c_void_p(0)
+    big = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+    assert lib.stein_comm_init(big, _lib.COMM_ID_BYTES, 2, 2, ctypes.byref(out)) == _lib.E_BADARG   # rank 2 of 2
+    assert lib.stein_comm_destroy(null) == _lib.E_BADARG
+    fake = (ctypes.c_ubyte * 64)()                                            # not a communicator: wrong magic word
+    hit = ctypes.c_int(0)
+    rc = lib.stein_rank_step(ctypes.cast(fake, ctypes.c_void_p), null, null, null, null, 8, 8, _lib.F32, null, null, null,
+                             null, null, null, 0, 0, ctypes.byref(hit), null)
+    assert rc == _lib.E_BADARG and b"communicator" in lib.stein_last_error()

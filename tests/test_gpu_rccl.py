@@ -1,4 +1,6 @@
-"""GPU: the multi-rank protocol of SvgdEngine driven through RCCL (torch.distributed backend "nccl") on ONE card.
+"""GPU: the multi-rank protocol of SvgdEngine driven through RCCL on ONE card -- by the library's own communicator
+(comm="native": stein_comm_init + stein_rank_step, the whole step one C call) and by torch.distributed's "nccl" backend
+between the rank segments (comm="torch").
 
 An 8-GPU node is not available to the builder, and every other multi-rank test uses gloo as the transport.  A
 one-rank "nccl" process group still sends every collective of the step through RCCL's API on the device's stream:
@@ -51,13 +53,15 @@ def _worker(rank, port, n, d, steps, out_dir):
         rng = np.random.default_rng(21)
         T0, G0 = rng.normal(size=(n, d)), rng.normal(size=(n, d))
         out = {}
-        for x3 in (False, True):
+        import itertools
+        for comm, x3 in itertools.product(("torch", "native"), (False, True)):
             for form in ("radix", "window"):
                 os.environ["STEIN_DIST_WINDOW"] = "1" if form == "window" else "0"
                 theta = torch.tensor(T0, dtype=torch.float32, device=dev)
                 score = torch.tensor(G0, dtype=torch.float32, device=dev)
-                eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True, x3=x3, small=False)
-                assert eng.sharded and eng.dist_window == (form == "window")
+                eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True, x3=x3, small=False,
+                                 comm=comm)
+                assert eng.sharded and eng.dist_window == (form == "window") and eng.comm == comm
                 gd = AdagradGradientDescent(learning_rate=1e-3)
                 ref = SvgdEngine(n, d, device=dev, x3=x3, small=False)       # single-rank staged path, same inputs
                 theta_r, gd_r = theta.clone(), AdagradGradientDescent(learning_rate=1e-3)
@@ -72,9 +76,14 @@ def _worker(rank, port, n, d, steps, out_dir):
                     assert abs(float(eng.sqnorm.item()) - float(ref.sqnorm.item())) <= 1e-6 * float(ref.sqnorm.item())
                     gd.apply_(theta, phi, eng.sqnorm)
                     gd_r.apply_(theta_r, phi_r, ref.sqnorm)
-                out["%s_%d" % (form, int(x3))] = dict(h2=h2s, hits=hits, errs=errs,
-                                                      theta_equal=bool(torch.equal(theta, theta_r)),
-                                                      theta_err=float((theta - theta_r).abs().max() / theta_r.abs().max()))
+                out["%s_%d_%s" % (form, int(x3), comm)] = dict(
+                    h2=h2s, hits=hits, errs=errs, theta_equal=bool(torch.equal(theta, theta_r)),
+                    theta_err=float((theta - theta_r).abs().max() / theta_r.abs().max()))
+                eng.close()
+        # "auto" on an nccl group with the HIP stages picks the library's communicator
+        eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True)
+        out["auto"] = eng.comm
+        eng.close()
         np.save(os.path.join(out_dir, "rccl.npy"), out, allow_pickle=True)
     finally:
         dist.destroy_process_group()
@@ -84,14 +93,21 @@ def test_protocol_through_rccl_on_one_rank(cuda, tmp_path):
     n, d, steps = 1280, 130, 6
     mp.spawn(_worker, args=(_free_port(), n, d, steps, str(tmp_path)), nprocs=1, join=True)
     out = np.load(os.path.join(str(tmp_path), "rccl.npy"), allow_pickle=True).item()
+    assert out["auto"] == "native"
+    for comm in ("torch", "native"):
+        for form in ("radix", "window"):
+            exact = out["%s_0_%s" % (form, comm)]          # fp32-MFMA kernels: the sharded protocol is bit-identical
+            assert all(a == b for a, b in exact["h2"]), exact["h2"]
+            assert all(e == 0.0 for e in exact["errs"]) and exact["theta_equal"], exact
+            split = out["%s_1_%s" % (form, comm)]          # split path: to rounding
+            assert all(abs(a - b) <= 2e-6 * b for a, b in split["h2"]), split["h2"]
+            assert max(split["errs"]) <= 5e-6 and split["theta_err"] <= 5e-6, split
+        for x3 in (0, 1):
+            hits = out["window_%d_%s" % (x3, comm)]["hits"]
+            assert hits[0] == 0 and sum(hits[2:]) >= 3, hits      # the window needs two medians of history, then hits
+            assert all(h == -1 for h in out["radix_%d_%s" % (x3, comm)]["hits"])
+    # the two ways of issuing the collectives run the same kernels on the same data: identical trajectories
     for form in ("radix", "window"):
-        exact = out[form + "_0"]                       # fp32-MFMA kernels: the sharded protocol is bit-identical
-        assert all(a == b for a, b in exact["h2"]), exact["h2"]
-        assert all(e == 0.0 for e in exact["errs"]) and exact["theta_equal"], exact
-        split = out[form + "_1"]                       # split path: to rounding
-        assert all(abs(a - b) <= 2e-6 * b for a, b in split["h2"]), split["h2"]
-        assert max(split["errs"]) <= 5e-6 and split["theta_err"] <= 5e-6, split
-    for x3 in (0, 1):
-        hits = out["window_%d" % x3]["hits"]
-        assert hits[0] == 0 and sum(hits[2:]) >= 3, hits      # the window needs two medians of history, then hits
-        assert all(h == -1 for h in out["radix_%d" % x3]["hits"])
+        for x3 in (0, 1):
+            a, b = out["%s_%d_torch" % (form, x3)], out["%s_%d_native" % (form, x3)]
+            assert a["h2"] == b["h2"] and a["errs"] == b["errs"] and a["hits"] == b["hits"], (form, x3)
