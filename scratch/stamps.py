@@ -16,14 +16,16 @@ t0 = time.time()
 while time.time() - t0 < 2.0:
     for _ in range(50): eng.compute_phi(T, G)
     torch.cuda.synchronize()
-buf = (ctypes.c_uint64 * 8)(); clk = (ctypes.c_uint64 * 2)()
-acc = np.zeros(8); cacc = np.zeros(2)
+lib.stein_debug_waves.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+buf = (ctypes.c_uint64 * 8)(); clk = (ctypes.c_uint64 * 2)(); wv = (ctypes.c_uint64 * 24)()
+acc = np.zeros(8); cacc = np.zeros(2); wacc = np.zeros(24)
 def mark(label):        # the staged calls: reset the counters right before the contraction, read them right after
     if label == "contract":
-        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1); lib.stein_debug_clock(clk, 1)
+        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1); lib.stein_debug_clock(clk, 1); lib.stein_debug_waves(wv, 1)
     elif label == "finish":
-        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0); lib.stein_debug_clock(clk, 0)
+        torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0); lib.stein_debug_clock(clk, 0); lib.stein_debug_waves(wv, 0)
         acc[:] += np.array(list(buf), dtype=np.float64); cacc[:] += np.array(list(clk), dtype=np.float64)
+        wacc[:] += np.array(list(wv), dtype=np.float64)
 reps = 8
 for _ in range(reps):
     for _ in range(30): eng.compute_phi(T, G)          # keep the chip loaded between the measured launches
@@ -38,3 +40,7 @@ for k, nm in enumerate(names):
     print("%-17s %8.1f shader cycles per k tile" % (nm, v[k] / nb / (jt / eng.split)))
 if clk[1]:
     print("in-kernel clock of the contraction (delta s_memtime / delta s_memrealtime x 100 MHz): %.3f GHz" % (clk[0] / clk[1] * 0.1))
+per = nb * (jt / eng.split)
+print("per wave (cycles per k tile): work | at the stage barrier")
+for w in range(12):
+    print("  wave %2d (%s): %7.1f | %7.1f" % (w, "producer" if w < 4 else "matrix", wacc[2 * w] / per, wacc[2 * w + 1] / per))

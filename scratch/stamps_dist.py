@@ -1,25 +1,40 @@
-"""Phase cycles of k_distance_x3 (wave 0 of every workgroup; -DSTEIN_STAMPS build)."""
+"""Phase cycles of k_distance_x3 (one wave per workgroup): -DSTEIN_STAMPS build.
+STAMPLIB=lib_stamps.so python scratch/stamps_dist.py n d"""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stein_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPLIB", "libsteinhip_stamps.so"))
-from stein_amd.engine import SvgdEngine
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPLIB", "lib_stamps.so"))
+from stein_amd.engine import SvgdEngine, _ptr, _dt, _stream
 lib = _lib.load()
 n, d = int(sys.argv[1]), int(sys.argv[2])
 T = torch.randn(n, d, device="cuda"); G = torch.randn(n, d, device="cuda")
-eng = SvgdEngine(n, d, device="cuda", x3=True)
+eng = SvgdEngine(n, d, device="cuda", x3=True, small=False)
 st = eng.stages
+for _ in range(30): eng.compute_phi(T, G)
 lib.stein_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 buf = (ctypes.c_uint64 * 8)()
-st.rownorms(T, n, d, eng.rownorm); st.x3_prepare(T, G, n, d, eng.planes)
-for rep in range(2):
-    st.median_begin(eng.hist, eng.select_state, n * n)
-    torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1)
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    st.distance_block(T, eng.rownorm, n, d, 0, n, eng.dist, eng.ld_dist, hist0=eng.hist[0], symmetric=True, planes=eng.planes)
-    e1.record(); torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0)
-v = np.array(list(buf), dtype=np.float64); nb = v[7]
-print("kernel ms", e0.elapsed_time(e1), "workgroups", nb)
-for k, nm in enumerate(["wait loads + LDS stores", "barriers", "issue + frags + MFMA", "epilogue"]):
-    print("%-26s %9.0f cycles per workgroup" % (nm, v[k] / nb))
-print("sum %9.0f" % (v[:4].sum() / nb))
+sel, spec, hist = eng.select_state, eng.spec_section, eng.hist
+state = sel.clone()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for sym in (True, False):
+    for mode in ("window", "plain"):
+        acc = np.zeros(8); ms = 0.0; reps = 5
+        for rep in range(reps):
+            for _ in range(10): eng.compute_phi(T, G)
+            sel.copy_(state)
+            if mode == "window": st.spec_begin(hist, sel, spec, n * n)
+            else: st.median_begin(hist, sel, n * n)
+            torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1)
+            fl = _lib.STAGE_SYMMETRIC if sym else 0
+            e0.record()
+            if mode == "window":
+                _lib.call("stein_distance_block_spec", _ptr(T), _ptr(eng.rownorm), n, d, 0, n, _dt(T), _ptr(eng.dist), eng.ld_dist,
+                          _ptr(hist[0]), _ptr(eng.planes), fl, _ptr(sel), _ptr(spec), _stream(T))
+            else:
+                st.distance_block(T, eng.rownorm, n, d, 0, n, eng.dist, eng.ld_dist, hist0=None, symmetric=sym, planes=eng.planes)
+            e1.record(); torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0)
+            acc += np.array(list(buf), dtype=np.float64); ms += e0.elapsed_time(e1)
+        nb = acc[7]
+        tot = acc[:4].sum() / nb
+        print("%-5s %-7s %.3f ms  wgs %6d | per workgroup (cycles): wait loads+LDS store %7.0f  barriers %7.0f  issue+MFMA %7.0f  epilogue %7.0f  total %7.0f"
+              % ("sym" if sym else "full", mode, ms / reps, nb / reps, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, tot), flush=True)

@@ -543,6 +543,7 @@ struct SteinLayout {
   size_t off[STEIN_WS_NSECTIONS];
   size_t total;
   int64_t ld_dist, split, sq_blocks, jchunk, tiles_m, cblocks;
+  int64_t phi_wide;   // split-precision contraction: 1 = 64-row x 512-column workgroups (k_phi_x3fs<NP, 4>), 0 = 128 x 256
   // split-precision planes (flags & STEIN_FLAG_X3): 16-bit [3 slots][rows][k] each, tile-major
   int64_t x3_rows, x3_dk;   // row-major theta planes: x3_rows x x3_dk  (distance operands)
   int64_t x3_dc, x3_nk;     // transposed planes of theta and of the score: x3_dc x x3_nk  (contraction B operand)

@@ -72,6 +72,12 @@ __device__ u64 g_stamps[8];
     st_last = now_;                                                               \
     __builtin_amdgcn_sched_barrier(0);                                            \
   } while (0)
+__device__ u64 g_wave[24];   // contraction, per wave of the workgroup: [2 w] cycles working, [2 w + 1] cycles at the stage barrier
+extern "C" int stein_debug_waves(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave), sizeof(u64) * 24) != hipSuccess) return -1;
+  if (reset) { u64 z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 __device__ u64 g_clock[2];   // sums over the sampled waves of (shader-clock ticks, 100 MHz real-time ticks) inside the contraction's main loop
 extern "C" int stein_debug_clock(u64* host_out, int reset) {
   if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock), sizeof(u64) * 2) != hipSuccess) return -1;
@@ -519,28 +525,37 @@ __device__ __forceinline__ void stream_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 // k tiles per pipeline stage (even: tile parity picks the register set) and the LDS of one k tile (NP planes, packed)
-template <int NP> struct FsGeom {
-  static constexpr int KT = 4;                        // 2 stages x KT x NP x 8 KB: 128 KB (NP 2), 64 KB (NP 1)
-  static constexpr int KTB = NP * XPLANE;
+// RB = 16-row blocks of the workgroup's tile: 8 -> 128 rows x 256 columns of [G | theta]; 4 -> 64 rows x 512 columns: the
+// P tile, whose exp / split work shares the SIMDs' issue slots with the MFMAs, is then built once per 512 columns, and
+// each D tile is read by one workgroup only.  The MFMA count per k tile and wave is the same (RB x CJ x products = 48).
+template <int NP, int RB> struct FsGeom {
+  static constexpr int KT = 4;                        // 2 stages x KT x NP x 8 KB: 128 KB (NP 2), 64 KB (NP 1); half for RB 4
+  static constexpr int ROWS = RB * 16;
+  static constexpr int PLN = ROWS * XROW;             // one plane of one k tile: [ROWS][64 B]
+  static constexpr int KTB = NP * PLN;                // one k tile in LDS: NP planes
   static constexpr int STAGE = KT * KTB;
+  static constexpr int CJ = 16 / RB;                  // 16-column blocks per matrix wave (8 waves: 256 or 512 columns)
+  static constexpr int PR = ROWS / 32;                // producer: rows lr + 32 p per thread and tile (4 columns each)
 };
 
-template <int NP>
+template <int NP, int RB>
 __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict__ D, long ldD,
                                                          const u16* __restrict__ Gt3, const u16* __restrict__ Tt3,
                                                          long ntj, const float* __restrict__ h2p,
                                                          float* __restrict__ OG, float* __restrict__ OT,
                                                          float* __restrict__ RS, int n, int d, int n_local,
-                                                         int tiles_m, int cblocks, int split, int jchunk,
-                                                         const float* __restrict__ sc, int dc) {
-  constexpr int FS_KT = FsGeom<NP>::KT, FS_KTB = FsGeom<NP>::KTB, FS_STAGE = FsGeom<NP>::STAGE;
+                                                         int tiles_m, int cblocks, int gblocks, int split,
+                                                         int jchunk, const float* __restrict__ sc, int dc) {
+  // cblocks: workgroups per row tile (grid); gblocks: 128-column blocks per matrix (G and theta each)
+  using Geo = FsGeom<NP, RB>;
+  constexpr int FS_KT = Geo::KT, FS_KTB = Geo::KTB, FS_STAGE = Geo::STAGE, PLN = Geo::PLN, CJ = Geo::CJ, PR = Geo::PR;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FS_STAGE];
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int cb = logical % cblocks;
   const int tile_m = (logical / cblocks) % tiles_m;
   const int z = logical / (cblocks * tiles_m);
-  const int i0 = tile_m * BM;
+  const int i0 = tile_m * Geo::ROWS;
   const int jbeg = z * jchunk;
   const int jend = min(n, jbeg + jchunk);
   const int ntile = jend > jbeg ? (jend - jbeg + BK - 1) / BK : 0;
@@ -574,32 +589,34 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     __builtin_amdgcn_s_setprio(STEIN_ABL_P_PRIO);
 #endif
     const int lr = pt >> 3, lc = (pt & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs[PR];
+#pragma unroll
+    for (int p = 0; p < PR; ++p) rs[p] = 0.f;
     // PD register sets (tile index mod PD picks the set): the loads of tile t + PD are issued as soon as tile t has been
     // turned into LDS data.  D streams from HBM (never re-used), so the loads need several tiles of lead
     constexpr int PD = FS_KT;   // 4; FS_KT % PD == 0 keeps the set index static
-    f32x4g rd[PD][4];
-    u32 doff[4];
+    f32x4g rd[PD][PR];
+    u32 doff[PR];
     const float cexp = -1.44269504088896341f / (2.f * *h2p);   // exp(-D/(2 h2)) = exp2(cexp * D)
     constexpr float pofs = (float)SplitTraits<NP>::pexp;        // P carries 2^pexp (undone by the out-scales)
     // the D tile (tile_m, j0 / 32) is one contiguous [128][32] block of the tile-major distance image (rows past
     // n_local exist as padding and only feed accumulator rows that are never stored)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) doff[p] = (u32)((lr + 32 * p) * DT_COLS + lc);
-    const float* __restrict__ drow = D + (size_t)tile_m * (ldD >> 5) * DT_ELEMS;
-    auto issue_loads = [&](int j0, f32x4g (&rd)[4]) {
+    for (int p = 0; p < PR; ++p) doff[p] = (u32)(((i0 & (DT_ROWS - 1)) + lr + 32 * p) * DT_COLS + lc);
+    const float* __restrict__ drow = D + (size_t)(i0 / DT_ROWS) * (ldD >> 5) * DT_ELEMS;
+    auto issue_loads = [&](int j0, f32x4g (&rd)[PR]) {
       const float* tile = drow + (size_t)(j0 >> 5) * DT_ELEMS;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) stream_load16(rd[p], tile, doff[p] * 4u);
+      for (int p = 0; p < PR; ++p) stream_load16(rd[p], tile, doff[p] * 4u);
     };
-    // before tile number v (in visit order) of the ntile is turned into LDS data: its 4 loads must have landed, the loads
-    // of the up to three later tiles already requested (4 each) stay in flight
-    auto wait_loads = [&](int v, f32x4g (&rd)[4]) {
+    // before tile number v (in visit order) of the ntile is turned into LDS data: its PR loads must have landed, the loads
+    // of the up to three later tiles already requested (PR each) stay in flight
+    auto wait_loads = [&](int v, f32x4g (&rd)[PR]) {
       const int later = ntile - v - 1;
       (void)rd;
-      if (later >= 3) stream_wait<12>();
-      else if (later == 2) stream_wait<8>();
-      else if (later == 1) stream_wait<4>();
+      if (later >= 3) stream_wait<3 * PR>();
+      else if (later == 2) stream_wait<2 * PR>();
+      else if (later == 1) stream_wait<PR>();
       else stream_wait<0>();
     };
     // registers of tile j0 -> LDS stage `buf`
@@ -608,17 +625,17 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // instructions (cvt -> fma_mix -> cvt -> store), and next to two matrix waves on the SIMD a dependent instruction waits
     // for the next free issue window: measured ~16 cycles per instruction.  Sixteen independent instructions per phase
     // fill the windows.
-    auto produce = [&](int j0, unsigned char* buf, const f32x4g (&rd)[4]) {
+    auto produce = [&](int j0, unsigned char* buf, const f32x4g (&rd)[PR]) {
       const bool full = j0 + BK <= jend;
-      float q[4][4];
+      float q[PR][4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < PR; ++p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[p][e] = __builtin_fmaf(cexp, rd[p][e], pofs);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef STEIN_ABL_P_NOEXP   // (ablation build: no transcendental)
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < PR; ++p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[p][e] = __builtin_amdgcn_exp2f(q[p][e]);
       __builtin_amdgcn_sched_barrier(0);
@@ -626,40 +643,40 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
         const int j = j0 + lc;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < PR; ++p)
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[p][e] = (j + e < jend) ? q[p][e] : 0.f;
       }
       if (NP >= 2) {
-        u32 hi[4][2], lo[4][2];
-        float r[4][4];
+        u32 hi[PR][2], lo[PR][2];
+        float r[PR][4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) rs[p] += (q[p][0] + q[p][1]) + (q[p][2] + q[p][3]);
+        for (int p = 0; p < PR; ++p) rs[p] += (q[p][0] + q[p][1]) + (q[p][2] + q[p][3]);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { hi[p][0] = cvt_pk_f16(q[p][0], q[p][1]); hi[p][1] = cvt_pk_f16(q[p][2], q[p][3]); }
+        for (int p = 0; p < PR; ++p) { hi[p][0] = cvt_pk_f16(q[p][0], q[p][1]); hi[p][1] = cvt_pk_f16(q[p][2], q[p][3]); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PR; ++p) {
           r[p][0] = f16_resid_lo(hi[p][0], q[p][0]); r[p][1] = f16_resid_hi(hi[p][0], q[p][1]);
           r[p][2] = f16_resid_lo(hi[p][1], q[p][2]); r[p][3] = f16_resid_hi(hi[p][1], q[p][3]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { lo[p][0] = cvt_pk_f16(r[p][0], r[p][1]); lo[p][1] = cvt_pk_f16(r[p][2], r[p][3]); }
+        for (int p = 0; p < PR; ++p) { lo[p][0] = cvt_pk_f16(r[p][0], r[p][1]); lo[p][1] = cvt_pk_f16(r[p][2], r[p][3]); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PR; ++p) {
           unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
 #ifdef STEIN_ABL_P_NOLDSW   // (ablation build: the producers write nothing to LDS)
           asm volatile("" :: "v"(hi[p][0]), "v"(hi[p][1]), "v"(lo[p][0]), "v"(lo[p][1]), "v"(dst));
 #else
           *reinterpret_cast<uint2*>(dst) = make_uint2(hi[p][0], hi[p][1]);
-          *reinterpret_cast<uint2*>(dst + XPLANE) = make_uint2(lo[p][0], lo[p][1]);
+          *reinterpret_cast<uint2*>(dst + PLN) = make_uint2(lo[p][0], lo[p][1]);
 #endif
         }
       } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PR; ++p) {
           // bf16 operands: K is rounded to bf16 once and BOTH uses of it (K.theta in the MFMA and rowsum(K) here) see
           // the rounded value, so the repulsion term sum_j K_ij (theta_i - theta_j) stays consistent
           unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;
@@ -717,10 +734,11 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       for (int k = 0; k < 3; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
       atomicAdd(&g_stamps[7], 1ull);
     }
+    if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[1] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[2]); }
 #endif
     if (cb == 0) {   // rowsum: the 8 threads of a row are 8 consecutive lanes
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < PR; ++p) {
         float sum = rs[p];
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
@@ -735,54 +753,43 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // than on 32x32x16 at the same cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7).
     const int ct = t - 256, lane = ct & 63, cw = ct >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int g = 2 * cb + (cw >> 2);   // this wave's 128-column block of [G | theta]
+    // this wave's 128-column block of [G | theta] and its CJ 16-column blocks inside it
+    const int g = RB == 8 ? 2 * cb + (cw >> 2) : 4 * cb + (cw >> 1);
+    const int wcol = RB == 8 ? (cw & 3) * 32 : (cw & 1) * 64;   // first column inside the block (16 CJ columns)
     // B fragment of (k tile kt, plane s, 16-column block jb): vb + ((kt * 3 + s) * 4096 + jb * 512) elements
     // (wave-uniform part, made provably so for the "s" operand of the streamed loads; per-lane byte offsets boff below)
-    const u16* vb_wave = (g < cblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E
-                                      : Tt3 + (size_t)(g - cblocks) * ntj * 3 * XTILE_E) +
-                         (size_t)(jbeg >> 5) * 3 * XTILE_E + (cw & 3) * 1024;
+    const u16* vb_wave = (g < gblocks ? Gt3 + (size_t)g * ntj * 3 * XTILE_E
+                                      : Tt3 + (size_t)(g - gblocks) * ntj * 3 * XTILE_E) +
+                         (size_t)(jbeg >> 5) * 3 * XTILE_E + wcol * 32;
     const u16* __restrict__ vb = reinterpret_cast<const u16*>(
         ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)((unsigned long long)vb_wave >> 32)) << 32) |
         (unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(unsigned long long)vb_wave));
-#ifdef STEIN_MFMA32   // (experiment build: the matrix waves on the 32x32x16 shape)
-    constexpr bool M32 = true;
-#else
-    constexpr bool M32 = false;
-#endif
-    u32 boff[2][3];
+    u32 boff[CJ][3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)   // 16x16x32: j = 16-column block; 32x32x16: j = k step (lane: column lane & 31, chunk 2 j + (lane >> 5))
+    for (int j = 0; j < CJ; ++j)   // j = 16-column block
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        boff[j][s] = M32 ? (u32)(((((lane & 31) >> 4) * 4 + 2 * j + (lane >> 5)) * 16 + (lane & 15)) * 8 + s * XTILE_E) * 2u
-                         : (u32)(lane * 8 + s * XTILE_E + j * 512) * 2u;
-    const int aoff32[2] = {(lane & 31) * XROW + pswz(lane & 31, 0 + (lane >> 5)), (lane & 31) * XROW + pswz(lane & 31, 2 + (lane >> 5))};
-    f32x16 acc32[4];
+      for (int s = 0; s < 3; ++s) boff[j][s] = (u32)(lane * 8 + s * XTILE_E + j * 512) * 2u;
+    const int aoff = l15 * XROW + pswz(l15, lq);   // A fragment of 16-row block ib, plane s: + ib * 1024 + s * PLN
+    f32x4 acc[RB][CJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
-    const int aoff = l15 * XROW + pswz(l15, lq);   // A fragment of 16-row block ib, plane s: + ib * 1024 + s * XPLANE
-    f32x4 acc[8][2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < CJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // two B register sets: the fragments of tile it+1 are requested at the top of tile it.  Held as 32-bit vectors
     // (loop-carried bf16 vectors get scalarised into 16-bit pieces by the compiler) and bit-cast at the MFMA.
-    u32x4 bX[2][3], bY[2][3];
-    auto load_b = [&](int tile, u32x4 (&b)[2][3]) {
+    u32x4 bX[CJ][3], bY[CJ][3];
+    auto load_b = [&](int tile, u32x4 (&b)[CJ][3]) {
       const u16* __restrict__ src = vb + (size_t)tile * 3 * XTILE_E;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < CJ; ++j)
 #pragma unroll
         for (int s = 0; s < NP; ++s) stream_load16(b[j][s], src, boff[j][s]);
     };
-    // before the MFMAs of a tile: its 2 NP fragment loads must have landed; `younger`: the next tile's 2 NP loads have
+    // before the MFMAs of a tile: its CJ NP fragment loads must have landed; `younger`: the next tile's CJ NP loads have
     // been requested already and stay in flight
-    auto wait_b = [&](bool younger, u32x4 (&b)[2][3]) {
+    auto wait_b = [&](bool younger, u32x4 (&b)[CJ][3]) {
       (void)b;
-      if (younger) stream_wait<2 * NP>();
+      if (younger) stream_wait<CJ * NP>();
       else stream_wait<0>();
     };
     // A fragments are read one 16-row block ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
@@ -793,39 +800,22 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       for (int s = 0; s < NP; ++s) { a[s] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(a[s])); }
 #else
 #pragma unroll
-      for (int s = 0; s < NP; ++s) a[s] = *reinterpret_cast<const u32x4*>(As + aoff + i * 16 * XROW + s * XPLANE);
+      for (int s = 0; s < NP; ++s) a[s] = *reinterpret_cast<const u32x4*>(As + aoff + i * 16 * XROW + s * PLN);
 #endif
     };
-    auto mma_tile = [&](const unsigned char* As, const u32x4 (&b)[2][3]) {
-      if constexpr (M32) {   // 4 row blocks of 32 x 2 k steps: fragments read one (block, step) ahead of their MFMAs
-        u32x4 a[2][3];
-        auto rd32 = [&](int q, u32x4 (&f)[3]) {   // q = 2 * row block + k step
-#pragma unroll
-          for (int s = 0; s < NP; ++s)
-            f[s] = *reinterpret_cast<const u32x4*>(As + aoff32[q & 1] + (q >> 1) * 32 * XROW + s * XPLANE);
-        };
-        rd32(0, a[0]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (q + 1 < 8) rd32(q + 1, a[(q + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          acc32[q >> 1] = x3_products<NP>(a[q & 1], b[q & 1], acc32[q >> 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        return;
-      }
+    auto mma_tile = [&](const unsigned char* As, const u32x4 (&b)[CJ][3]) {
       u32x4 a[2][3];
       read_a(As, 0, a[0]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i + 1 < 8) read_a(As, i + 1, a[(i + 1) & 1]);
+      for (int i = 0; i < RB; ++i) {
+        if (i + 1 < RB) read_a(As, i + 1, a[(i + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef STEIN_ABL_C_NOMFMA   // (ablation build: the matrix waves read their operands and issue no MFMA)
 #pragma unroll
         for (int s = 0; s < NP; ++s) asm volatile("" :: "v"(a[i & 1][s]), "v"(b[0][s]), "v"(b[1][s]));
 #else
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = x3_products16<NP>(a[i & 1], b[j], acc[i][j]);
+        for (int j = 0; j < CJ; ++j) acc[i][j] = x3_products16<NP>(a[i & 1], b[j], acc[i][j]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -858,6 +848,12 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
         STAMP(3);
         wait_b(kLoadV && n1, bX);
         STAMP(0);   // diagnostic builds: waiting for this tile's V fragments
+        // The two matrix waves of a SIMD (cw and cw + 4) take turns at the higher issue priority, tile by tile.  At equal
+        // priority the older wave wins every arbitration: it ran ahead (1460 vs 2070 cycles per k tile, per-wave stamps)
+        // and idled at the stage barrier while the younger one finished alone.  Measured -2 % on the launch.
+#ifndef STEIN_NO_PRIO_ALT   // (A/B builds)
+        if (cw >> 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+#endif
         mma_tile(As + u * FS_KTB, bX);
         if (n1) {
           const bool n2 = after(u + 2) < ntile;
@@ -865,6 +861,9 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
           STAMP(3);
           wait_b(kLoadV && n2, bY);
           STAMP(0);
+#ifndef STEIN_NO_PRIO_ALT
+          if (cw >> 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
           mma_tile(As + (u + 1) * FS_KTB, bY);
         }
       }
@@ -879,6 +878,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       atomicAdd(&g_clock[0], clk1 - clk0);
       atomicAdd(&g_clock[1], rt1 - rt0);
     }
+    if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[3] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[4]); }
     if (t == 256)
       for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
     if (t == 512) {   // the second matrix wave of the same SIMD
@@ -886,30 +886,17 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       atomicAdd(&g_stamps[6], st_acc[0]);   // time spent waiting for the B fragments at the top of a tile
     }
 #endif
-    float* __restrict__ Oz = (g < cblocks ? OG : OT) + (size_t)z * n_local * d;
-    const int cbase = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + l15;
-    const float* __restrict__ osc = sc + (g < cblocks ? 2 : 3) * dc;   // out-scales of this wave's matrix
-    if constexpr (M32) {
-      const int col = (g < cblocks ? g : g - cblocks) * BN + (cw & 3) * 32 + (lane & 31);
-      if (col < d) {
-        const float os = osc[col];
+    if (g >= 2 * gblocks) return;   // (an odd block count leaves the last workgroup's upper waves without columns)
+    float* __restrict__ Oz = (g < gblocks ? OG : OT) + (size_t)z * n_local * d;
+    const int cbase = (g < gblocks ? g : g - gblocks) * BN + wcol + l15;
+    const float* __restrict__ osc = sc + (g < gblocks ? 2 : 3) * dc;   // out-scales of this wave's matrix
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = i0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (row < n_local) Oz[(size_t)row * d + col] = acc32[i][e] * os;
-          }
-      }
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < CJ; ++j) {
       const int col = cbase + j * 16;
       if (col >= d) continue;
       const float os = osc[col];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = i0 + i * 16 + 4 * lq + e;
@@ -1010,11 +997,16 @@ int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* pl
   const u16* Tt3 = reinterpret_cast<const u16*>(planes + L.x3_tt3);
   const u16* Gt3 = reinterpret_cast<const u16*>(planes + L.x3_gt3);
   const float* sc = reinterpret_cast<const float*>(planes + L.x3_sc);
-  const long nblk = (long)L.tiles_m * L.cblocks * L.split;
-#define X3_PHI(NP) hipLaunchKernelGGL(k_phi_x3fs<NP>, dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3, (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)L.tiles_m, (int)L.cblocks, (int)L.split, (int)L.jchunk, sc, (int)L.x3_dc)
-  switch (split_kind(dtype)) {
-    case 1: X3_PHI(1); break;
-    default: X3_PHI(2); break;
+  // 64-row x 512-column workgroups when the 128-column blocks of [G | theta] fill them (an even block count per matrix)
+  const bool wide = L.phi_wide != 0;
+  const long tm = wide ? (n_local + 63) / 64 : L.tiles_m, cbk = wide ? L.cblocks / 2 : L.cblocks;
+  const long nblk = tm * cbk * L.split;
+#define X3_PHI(NP, RB) hipLaunchKernelGGL((k_phi_x3fs<NP, RB>), dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3, (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)tm, (int)cbk, (int)L.cblocks, (int)L.split, (int)L.jchunk, sc, (int)L.x3_dc)
+  switch (split_kind(dtype) * 2 + (wide ? 1 : 0)) {
+    case 2: X3_PHI(1, 8); break;
+    case 3: X3_PHI(1, 4); break;
+    case 5: X3_PHI(2, 4); break;
+    default: X3_PHI(2, 8); break;
   }
 #undef X3_PHI
   LAUNCH_CHECK("k_phi_x3fs");

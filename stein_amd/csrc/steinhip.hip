@@ -1077,6 +1077,14 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   // workgroups per unit of split and resident workgroups per round: the fp32 kernel tiles [G | theta] in 128-column
   // blocks at 3 workgroups per CU; the split-precision kernel pairs the blocks up (256 columns) at 1 workgroup per CU
   const bool x3 = (flags & STEIN_FLAG_X3) != 0;
+  // the split kernel's 64-row x 512-column form (k_phi_x3fs<NP, 4>: P built once per 512 columns, every D tile read by one
+  // workgroup; needs an even number of 128-column blocks per matrix; same workgroup count and partial layout).  Measured
+  // equal to the 128 x 256 form within +-1 % at C3 and C4 (scratch/README.md), so the shipped library keeps one form.
+#ifdef STEIN_PHI_WIDE   // (A/B builds)
+  L->phi_wide = (x3 && L->cblocks % 2 == 0) ? 1 : 0;
+#else
+  L->phi_wide = 0;
+#endif
   const int64_t base = x3 ? L->tiles_m * L->cblocks : L->tiles_m * 2 * L->cblocks;
   const int64_t jt = (n + BK - 1) / BK;  // j tiles
   // k_phi_partial runs 3 workgroups per CU (156 registers): 768 resident blocks.  Every block does the same
