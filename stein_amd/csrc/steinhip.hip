@@ -497,9 +497,17 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
   const u64 total = sp->total, below = below_s;
   const u64 r0 = (total & 1ull) ? total / 2 : total / 2 - 1, r1 = total / 2;
   if (r0 < below || r1 - below > 0xfffffff0ull) return false;   // the target lies below the window
-  for (u32 i = t; i < cnt; i += 1024) {
-    const u64 e = buf[i];
-    atomicAdd(&h1[((u32)(e >> 2) - lo) >> 8], (u32)e & 3u);
+  // A window narrower than 256 keys puts EVERY entry into one or two bins of this pass: 2*10^4 same-address LDS atomics
+  // were ~10 us of this one-workgroup kernel.  Lanes that share the leader's bin are merged into one atomic per wave
+  // (hist_add; the weights are 1 or 2, one call each).
+  for (u32 i0 = 0; i0 < cnt; i0 += 1024) {   // wave-uniform trip count: the ballots need every lane
+    const u32 i = i0 + (u32)t;
+    const bool ok = i < cnt;
+    const u64 e = ok ? buf[i] : 0ull;
+    const u32 hb = (((u32)(e >> 2) - lo) >> 8) & 255u, w = (u32)e & 3u;
+    hist_add(h1, hb, ok && w == 2u, t & 63, 2u);
+    hist_add(h1, hb, ok && w == 1u, t & 63, 1u);
+    if (ok && w == 3u) atomicAdd(&h1[hb], 3u);   // (no producer writes weight 3; kept exact all the same)
   }
   __syncthreads();
   spec_locate(h1, (u32)(r0 - below), scan, &sel[0], &sel[2]);
