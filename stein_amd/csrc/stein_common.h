@@ -225,6 +225,12 @@ constexpr int EPI_STAGE_LD = 132;                             // floats per stag
 constexpr int EPI_STAGE_BYTES = 64 * EPI_STAGE_LD * 4;        // 33792: half tile [64 rows][128 columns]
 constexpr int EPI_LDS_BYTES = EPI_STAGE_BYTES + 8192 + 64 + 1024;   // + histogram OR window queue, counters, norms: 43072
 
+// 16-byte store of four consecutive distances.  (Streaming `nt` stores were measured: on the mirror stores, whose 32-byte
+// pieces rely on the L2 to merge into lines, the kernel took twice as long; on the row stores alone -1 %, within noise.)
+__device__ __forceinline__ void store_d4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
 // the staged half tile (phase p: rows wy*64 + p*32 + 0..31 of the tile, staged as row wy*32 + r) -> D, 16 bytes per lane
 __device__ __forceinline__ void distance_store_rows(const float* __restrict__ stage, float* __restrict__ D, long ntc,
                                                     int tile_m, int brow0, int p) {
@@ -234,8 +240,8 @@ __device__ __forceinline__ void distance_store_rows(const float* __restrict__ st
     const int sr = (t >> 5) + 8 * k;
     const int row = tile_m * BM + (sr >> 5) * 64 + p * 32 + (sr & 31);
 #ifndef STEIN_ABL_NOROWSTORE
-    *reinterpret_cast<float4*>(D + d_index(row, brow0 + 4 * f4, ntc)) =
-        *reinterpret_cast<const float4*>(stage + sr * EPI_STAGE_LD + 4 * f4);
+    const float4 v4 = *reinterpret_cast<const float4*>(stage + sr * EPI_STAGE_LD + 4 * f4);
+    store_d4(D + d_index(row, brow0 + 4 * f4, ntc), v4.x, v4.y, v4.z, v4.w);
 #else   // (ablation build, never shipped)
     const float4 keep = *reinterpret_cast<const float4*>(stage + sr * EPI_STAGE_LD + 4 * f4);
     asm volatile("" :: "v"(keep.x), "v"(keep.y), "v"(keep.z), "v"(keep.w), "v"(row));
@@ -360,7 +366,7 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
         // one 32-column tile, 16-byte aligned).  Entries past n land in padding, which no later stage reads.
 #ifndef STEIN_ABL_NOMIRROR
         if (MIRROR && cok && (!PRED || lrow4 < n_local))
-          *reinterpret_cast<float4*>(D + d_index(col, lrow4, ntc)) = make_float4(v[0], v[1], v[2], v[3]);
+          store_d4(D + d_index(col, lrow4, ntc), v[0], v[1], v[2], v[3]);
 #endif
       }
     }

@@ -80,6 +80,23 @@ def _worker(rank, port, n, d, steps, out_dir):
                     h2=h2s, hits=hits, errs=errs, theta_equal=bool(torch.equal(theta, theta_r)),
                     theta_err=float((theta - theta_r).abs().max() / theta_r.abs().max()))
                 eng.close()
+        # bf16 particles (BASELINE config 2's input format) and the optional dK output through stein_rank_step
+        os.environ["STEIN_DIST_WINDOW"] = "1"
+        tb = torch.tensor(T0, dtype=torch.float32, device=dev).bfloat16()
+        gb = torch.tensor(G0, dtype=torch.float32, device=dev).bfloat16()
+        eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True, dtype=torch.bfloat16, small=False,
+                         comm="native")
+        ref = SvgdEngine(n, d, device=dev, dtype=torch.bfloat16, small=False)
+        dK, dK_r = torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
+        errs = []
+        for _ in range(3):
+            phi = eng.compute_phi(tb, gb, dK_out=dK)
+            phi_r = ref.compute_phi(tb, gb, dK_out=dK_r, mark=lambda label: None)
+            torch.cuda.synchronize()
+            errs.append((float((phi - phi_r).norm() / phi_r.norm()), float((dK - dK_r).norm() / dK_r.norm()),
+                         float(eng.h2.item()), float(ref.h2.item())))
+        out["bf16"] = errs
+        eng.close()
         # "auto" on an nccl group with the HIP stages picks the library's communicator
         eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True)
         out["auto"] = eng.comm
@@ -94,6 +111,8 @@ def test_protocol_through_rccl_on_one_rank(cuda, tmp_path):
     mp.spawn(_worker, args=(_free_port(), n, d, steps, str(tmp_path)), nprocs=1, join=True)
     out = np.load(os.path.join(str(tmp_path), "rccl.npy"), allow_pickle=True).item()
     assert out["auto"] == "native"
+    for e_phi, e_dk, h2a, h2b in out["bf16"]:          # bf16: K is rounded to bf16 in both runs; row block vs symmetric order
+        assert e_phi <= 4e-3 and e_dk <= 4e-3 and abs(h2a - h2b) <= 1e-6 * h2b, out["bf16"]
     for comm in ("torch", "native"):
         for form in ("radix", "window"):
             exact = out["%s_0_%s" % (form, comm)]          # fp32-MFMA kernels: the sharded protocol is bit-identical
