@@ -379,7 +379,7 @@ def main():
     }
     if world > 1:
         out["collectives"] = {"issued_by": {"native": "libsteinhip (own RCCL communicator, stein_rank_step: one C call per step)",
-                                            "torch": "torch.distributed (nccl = RCCL) between the rank segments"}[res["comm"]],
+                                            "torch": "torch.distributed (backend %s) between the rank segments" % dist.get_backend(group)}[res["comm"]],
                               "note": res["comm_note"], "crosscheck_vs_torch_collectives": res["comm_crosscheck"]}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, res["T64"], res["G64"], args.cpu_rows)
