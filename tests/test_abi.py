@@ -145,3 +145,11 @@ def test_communicator_entry_points_check_their_arguments_without_rccl():
     rc = lib.stein_rank_step(ctypes.cast(fake, ctypes.c_void_p), null, null, null, null, 8, 8, _lib.F32, null, null, null,
                              null, null, null, 0, 0, ctypes.byref(hit), null)
     assert rc == _lib.E_BADARG and b"communicator" in lib.stein_last_error()
+
+
+def test_c_host_example_builds_as_plain_c11(tmp_path):
+    """include/steinhip.h is a C header and every entry point the C host uses links: examples/c_host/svgd_steps.c
+    compiles with gcc -std=c11 -Wall -Werror (no GPU needed to build; tests/test_gpu_c_host.py runs it)."""
+    import __graft_entry__ as ge
+    exe = ge.build_c_host(str(tmp_path / "svgd_steps"))
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
