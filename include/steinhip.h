@@ -59,9 +59,15 @@ enum {
 };
 /* flags for the staged distance / histogram calls */
 enum {
-  STEIN_STAGE_SYMMETRIC = 1 /* the block is the whole n x n matrix (row0 = 0, n_local = n): compute / count only the
-                               upper triangle; the distance pass stores each off-diagonal tile twice (mirrored) and
-                               the histograms weigh off-diagonal entries by 2.  Results are identical. */
+  STEIN_STAGE_SYMMETRIC = 1, /* the block is the whole n x n matrix (row0 = 0, n_local = n): compute / count only the
+                                upper triangle; the histograms weigh off-diagonal entries by 2.  On the fp32-MFMA path
+                                (x3_planes = NULL) the distance pass stores each off-diagonal tile twice (mirrored): a
+                                full image.  On the split path it stores ONLY the 128 x 128 tiles on and above the
+                                diagonal; pass STEIN_STAGE_UPPER with that image to its readers.  Results are identical. */
+  STEIN_STAGE_UPPER = 2      /* readers of a distance image (stein_contract_partial, stein_kernel_contract,
+                                stein_kernel_matrix): the image holds only the tiles on and above the diagonal of the
+                                whole symmetric matrix, as stein_distance_block(STEIN_STAGE_SYMMETRIC) with x3_planes
+                                leaves it; entries of the other tiles are read from their mirror images */
 };
 
 /* Workspace sections reported by stein_workspace_layout (byte offsets into the workspace). */
@@ -189,7 +195,8 @@ int stein_median_resolve(const void* hist, int level, int64_t n, void* select_st
 
 /* K = exp(-D / h2 / 2)               squared_exponential_kernel.py:22 (optional output) */
 int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n,
-                        const float* h2_dev, float* K_out, int64_t ld_K, void* stream);
+                        const float* h2_dev, float* K_out, int64_t ld_K, int dist_flags /* 0 or STEIN_STAGE_UPPER */,
+                        void* stream);
 
 /* phi rows of this rank:  (K.G + (rowsum(K) theta - K.theta)/h2) / n
  * squared_exponential_kernel.py:23,32 (dK) and abstract_stein_sampler.py:105 (phi).
@@ -197,7 +204,8 @@ int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int
 int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
                           int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
-                          const void* x3_planes, void* workspace, size_t ws_bytes, void* stream);
+                          const void* x3_planes, void* workspace, size_t ws_bytes, int dist_flags /* 0 or STEIN_STAGE_UPPER */,
+                          void* stream);
 
 /* The two halves of stein_kernel_contract, exposed so a harness can time the MFMA kernel on its own:
  *   partial : k_phi_partial only (fills the PART_G / PART_T / PART_RS workspace sections)
@@ -205,7 +213,7 @@ int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_
 int stein_contract_partial(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
                            int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                            const float* h2_dev, const void* x3_planes, void* workspace, size_t ws_bytes,
-                           void* stream);
+                           int dist_flags /* 0 or STEIN_STAGE_UPPER */, void* stream);
 int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                           const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
                           void* workspace, size_t ws_bytes, int flags /* same STEIN_FLAG_* as the partial */,

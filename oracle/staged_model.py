@@ -208,7 +208,7 @@ class NumpyStages:
             h2.numpy()[0] = self._st.h2
             median.numpy()[0] = self._st.median
 
-    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None):
+    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None, upper=False):
         K = np.exp(-D.numpy()[:n_local, :n] / h2.numpy()[0] / np.float32(2)).astype(np.float64)
         self._partial = (K @ G.numpy().astype(np.float64), K @ T.numpy().astype(np.float64), K.sum(axis=1))
 
@@ -222,11 +222,11 @@ class NumpyStages:
         if dK is not None:
             dK.numpy()[:] = dk
 
-    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
+    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None, upper=False):
         self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws)
         self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws)
 
-    def kernel_matrix(self, D, ld, n_local, n, h2, K):
+    def kernel_matrix(self, D, ld, n_local, n, h2, K, upper=False):
         K.numpy()[:] = np.exp(-D.numpy()[:n_local, :n] / h2.numpy()[0] / np.float32(2))
 
     def svgd_phi(self, T, G, n, d, phi, h2, sqnorm, K, dK, ws, flags=0):

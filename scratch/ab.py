@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from stein_amd import _lib
 _lib.LIB_PATH = LIBPATH
 from stein_amd.engine import SvgdEngine
+if "noupper" in _lib.LIB_PATH: SvgdEngine._full_distance_image = True   # -DSTEIN_NO_UPPER builds
 n, d = N, D
 torch.manual_seed(0)
 T = torch.randn(n, d, device="cuda"); G = torch.randn(n, d, device="cuda")

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stein_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPLIB", "lib_stamps.so"))
 from stein_amd.engine import SvgdEngine
+if "noupper" in _lib.LIB_PATH: SvgdEngine._full_distance_image = True   # -DSTEIN_NO_UPPER builds
 lib = _lib.load()
 lib.stein_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 lib.stein_debug_clock.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]

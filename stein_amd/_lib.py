@@ -19,6 +19,7 @@ WSX_LD_DIST, WSX_SPLIT, WSX_SQ_BLOCKS, WSX_HIST_BINS = range(4)
 WSX_N = 4
 HIST_BINS, HIST_LEVELS = 2048, 3
 STAGE_SYMMETRIC = 1
+STAGE_UPPER = 2
 FLAG_X3 = 1
 FLAG_TIMING = 4
 FLAG_TILED = 8
@@ -66,9 +67,9 @@ _SIGNATURES = {
     "stein_median_begin": [_vp, _vp, _i64, _vp],
     "stein_median_hist_pass": [_vp, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp],
     "stein_median_resolve": [_vp, _int, _i64, _vp, _vp, _vp, _vp],
-    "stein_kernel_matrix": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp],
-    "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "stein_contract_partial": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp],
+    "stein_kernel_matrix": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _int, _vp],
+    "stein_kernel_contract": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
+    "stein_contract_partial": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_contract_finish": [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp],
     "stein_apply_adagrad": [_vp, _vp, _int, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp],
     "stein_apply_adam": [_vp, _vp, _int, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],

@@ -256,7 +256,11 @@ struct SpecCtx {   // per-thread view of the speculative window (SPEC epilogues 
   u32 below;       // this thread's weight of entries below the window
 };
 
-template <bool MIRROR, bool PRED, bool DIAG, bool HIST, bool SPEC>
+// MIRROR: an entry above the diagonal also stands for its mirror image (weight 2 in every count); STOREM: the mirror
+// image is also STORED (the fp32-MFMA path: D is then a full symmetric image).  The split path stores only the tiles on
+// and above the diagonal (STOREM = false): its contraction reads the others transposed (stein_x3.hip), which saves half
+// of the distance pass's 4 n^2 bytes of stores -- the pass is bound by them.
+template <bool MIRROR, bool PRED, bool DIAG, bool HIST, bool SPEC, bool STOREM>
 __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2], u32* hl, float* __restrict__ D, int n,
                                                        int n_local, long ldD, int tile_m, int brow0, u32 base,
                                                        u64& packed, float two_s,
@@ -365,7 +369,7 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
         // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (lrow4 % 4 == 0: they stay inside
         // one 32-column tile, 16-byte aligned).  Entries past n land in padding, which no later stage reads.
 #ifndef STEIN_ABL_NOMIRROR
-        if (MIRROR && cok && (!PRED || lrow4 < n_local))
+        if (MIRROR && STOREM && cok && (!PRED || lrow4 < n_local))
           store_d4(D + d_index(col, lrow4, ntc), v[0], v[1], v[2], v[3]);
 #endif
       }
@@ -397,7 +401,7 @@ __device__ __forceinline__ EpiPrefetch distance_epilogue_prefetch(const float* _
 // `lds` is the kernel's shared array, EPI_LDS_BYTES at least, which the caller no longer needs (all waves must be past
 // their last LDS read): half-tile staging, 8 KB histogram, counters, window queue, row / column norms.
 // spec != NULL needs hist0 != NULL.
-template <bool SYM>
+template <bool SYM, bool STORE_MIRROR = SYM>
 __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32* lds, float* __restrict__ D, int n,
                                                   int n_local, long ldD, int tile_m, int tile_n,
                                                   u64* __restrict__ hist0,
@@ -444,13 +448,13 @@ __device__ __forceinline__ void distance_epilogue(const f32x16 (&acc)[2][2], u32
 #define STEIN_EPI_I(MIRROR, PRED, DIAG, I)                                                                             \
   do {                                                                                                                 \
     if (window)                                                                                                        \
-      distance_epilogue_body<MIRROR, PRED, DIAG, false, true>(acc, hl, D, n, n_local, ldD, tile_m, brow0,             \
+      distance_epilogue_body<MIRROR, PRED, DIAG, false, true, STORE_MIRROR>(acc, hl, D, n, n_local, ldD, tile_m, brow0,             \
                                                               base, packed, two_s, sx, rr, rc, I, stage);             \
     else if (hist)                                                                                                     \
-      distance_epilogue_body<MIRROR, PRED, DIAG, true, false>(acc, hl, D, n, n_local, ldD, tile_m, brow0,             \
+      distance_epilogue_body<MIRROR, PRED, DIAG, true, false, STORE_MIRROR>(acc, hl, D, n, n_local, ldD, tile_m, brow0,             \
                                                               base, packed, two_s, sx, rr, rc, I, stage);             \
     else                                                                                                               \
-      distance_epilogue_body<MIRROR, PRED, DIAG, false, false>(acc, hl, D, n, n_local, ldD, tile_m, brow0,            \
+      distance_epilogue_body<MIRROR, PRED, DIAG, false, false, STORE_MIRROR>(acc, hl, D, n, n_local, ldD, tile_m, brow0,            \
                                                                base, packed, two_s, sx, rr, rc, I, stage);            \
   } while (0)
   const long ntc = ldD >> 5;

@@ -11,4 +11,5 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
                       hipStream_t stream, SpecState* spec = nullptr, u64* spec_buf = nullptr);
 int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L, int dtype,
                               const float* h2_dev, float* OG, float* OT, float* RS, int64_t n, int64_t d,
-                              int64_t n_local, hipStream_t stream);
+                              int64_t n_local, hipStream_t stream, bool upper /* dist holds only the tiles on and above
+                              the diagonal of a symmetric block (what stein_x3_distance(symmetric) stores) */);

@@ -458,8 +458,14 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
     STAMP(1);
   }
 #ifndef STEIN_ABL_NOEPI
-  distance_epilogue<SYM>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
-                         two_s_v, spec, spec_buf);
+  // SYM: only the tiles on and above the diagonal are stored (the contraction reads the others transposed)
+#ifdef STEIN_NO_UPPER   // (A/B build: the full mirrored image)
+  distance_epilogue<SYM, SYM>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
+                              two_s_v, spec, spec_buf);
+#else
+  distance_epilogue<SYM, false>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
+                                two_s_v, spec, spec_buf);
+#endif
 #else
   {
     float sum = two_s_v + pf.norm;
@@ -545,7 +551,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
                                                          float* __restrict__ OG, float* __restrict__ OT,
                                                          float* __restrict__ RS, int n, int d, int n_local,
                                                          int tiles_m, int cblocks, int gblocks, int split,
-                                                         int jchunk, const float* __restrict__ sc, int dc) {
+                                                         int jchunk, const float* __restrict__ sc, int dc,
+                                                         int upper) {
   // cblocks: workgroups per row tile (grid); gblocks: 128-column blocks per matrix (G and theta each)
   using Geo = FsGeom<NP, RB>;
   constexpr int FS_KT = Geo::KT, FS_KTB = Geo::KTB, FS_STAGE = Geo::STAGE, PLN = Geo::PLN, CJ = Geo::CJ, PR = Geo::PR;
@@ -579,6 +586,15 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     return st2 * FS_KT + ((st2 + 1) * FS_KT <= ntile ? ((u2 + rot) & (FS_KT - 1)) : u2);
   };
 
+  // upper (single rank, D holds only the 128 x 128 tiles on and above the diagonal): the k tiles left of this row tile's
+  // diagonal block are read from their mirror image D[j][i].  The producers gather such a tile with a row-per-lane-group
+  // map (below) that leaves every thread holding 4 consecutive j of 4 rows i, so it is written into the SAME natural LDS
+  // image with the same number of 8-byte stores: the matrix waves do not know the difference.  The choice is per pipeline
+  // stage (FS_KT k tiles = 128 columns; the host keeps jbeg a multiple of 128, so a stage never straddles the diagonal
+  // block): the first ntr stages of the j range are mirrored ones.
+  const bool up = RB == 8 && upper != 0;
+  const int ntr = up ? max(0, min(nstage, (i0 - jbeg) / (FS_KT * BK))) : 0;
+
   const int t = threadIdx.x;
   // The two roles run separate loops (so neither carries the other's registers) with the same number of
   // barriers: one after the prologue, one per k tile.  The role test is wave-uniform (waves 0-3 / 4-11).
@@ -604,10 +620,24 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #pragma unroll
     for (int p = 0; p < PR; ++p) doff[p] = (u32)(((i0 & (DT_ROWS - 1)) + lr + 32 * p) * DT_COLS + lc);
     const float* __restrict__ drow = D + (size_t)(i0 / DT_ROWS) * (ldD >> 5) * DT_ELEMS;
-    auto issue_loads = [&](int j0, f32x4g (&rd)[PR]) {
-      const float* tile = drow + (size_t)(j0 >> 5) * DT_ELEMS;
+    // mirrored source (upper): wave w gathers from mirror tile w (columns i0 + 32 w .. + 31); thread (c = pt & 7,
+    // jq = (pt >> 3) & 7) loads D[j0 + 4 jq + u][i0 + 4 ig .. + 3], ig = 8 w + c, u = 0..3: a quarter wave reads two full
+    // 128-byte lines, like the natural map (lanes along j first made every quarter wave touch eight lines: the producers
+    // took 2500 instead of 1500 cycles per k tile).  Afterwards the thread holds P(i = 4 ig + e, j = 4 jq + u): four
+    // consecutive j of four rows = one 8-byte LDS store per row and plane at row 4 ig + e, byte 8 jq of the natural image
+    const int jq = (pt >> 3) & 7, ig = (pt >> 6) * 8 + (pt & 7);
+    u32 doff_tr[PR];
 #pragma unroll
-      for (int p = 0; p < PR; ++p) stream_load16(rd[p], tile, doff[p] * 4u);
+    for (int u = 0; u < PR; ++u) doff_tr[u] = (u32)((ig >> 3) * DT_ELEMS + (4 * jq + u) * DT_COLS + 4 * (ig & 7)) * 4u;
+    const long ntc_d = ldD >> 5;
+    float rst[4] = {0.f, 0.f, 0.f, 0.f};   // row sums over the mirrored tiles: rows i0 + 4 ig + e
+    // one call site for both sources (base and offsets selected first): a load instruction in each arm of a branch would
+    // let the compiler reconcile the two destination registers with copies of registers that are still in flight
+    auto request = [&](int j0, bool tr, f32x4g (&rd)[PR]) {
+      const float* tile = tr ? D + ((size_t)(j0 >> 7) * ntc_d + 4 * (size_t)(i0 / DT_ROWS)) * DT_ELEMS + (j0 & 127) * DT_COLS
+                             : drow + (size_t)(j0 >> 5) * DT_ELEMS;
+#pragma unroll
+      for (int p = 0; p < PR; ++p) stream_load16(rd[p], tile, tr ? doff_tr[p] : doff[p] * 4u);
     };
     // before tile number v (in visit order) of the ntile is turned into LDS data: its PR loads must have landed, the loads
     // of the up to three later tiles already requested (PR each) stay in flight
@@ -687,6 +717,58 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
         }
       }
     };
+    // the same for a tile read from its mirror image (always a full tile): rd[u][e] = D[j = 4 jq + u][i = 4 ig + e].
+    // (The row sums below run along e, i.e. over adjacent registers: under plain -O3 the SLP vectoriser turned them into
+    // v_pk_add_f32, and eight packed adds per k tile beside the MFMAs cost the launch 0.07 ms -- the library is built with
+    // -fno-slp-vectorize, __graft_entry__.py.)
+    auto produce_tr = [&](unsigned char* buf, const f32x4g (&rd)[PR]) {
+      if constexpr (RB == 8) {
+        float q[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[u][e] = __builtin_fmaf(cexp, rd[u][e], pofs);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[u][e] = __builtin_amdgcn_exp2f(q[u][e]);
+        __builtin_amdgcn_sched_barrier(0);
+        u32 hi[4][2], lo[4][2];   // [row e][j pair]
+        if (NP >= 2) {
+          float r[4][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rst[e] += (q[0][e] + q[1][e]) + (q[2][e] + q[3][e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hi[e][0] = cvt_pk_f16(q[0][e], q[1][e]); hi[e][1] = cvt_pk_f16(q[2][e], q[3][e]); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            r[e][0] = f16_resid_lo(hi[e][0], q[0][e]); r[e][1] = f16_resid_hi(hi[e][0], q[1][e]);
+            r[e][2] = f16_resid_lo(hi[e][1], q[2][e]); r[e][3] = f16_resid_hi(hi[e][1], q[3][e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lo[e][0] = cvt_pk_f16(r[e][0], r[e][1]); lo[e][1] = cvt_pk_f16(r[e][2], r[e][3]); }
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {   // bf16: the row sums see the ROUNDED values, as in the natural tiles
+            hi[e][0] = cvt_pk_bf16(q[0][e], q[1][e]); hi[e][1] = cvt_pk_bf16(q[2][e], q[3][e]);
+            lo[e][0] = lo[e][1] = 0u;
+            rst[e] += (__uint_as_float(hi[e][0] << 16) + __uint_as_float(hi[e][0] & 0xffff0000u)) +
+                      (__uint_as_float(hi[e][1] << 16) + __uint_as_float(hi[e][1] & 0xffff0000u));
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 4 * ig + e;   // (row >> 2) & 3 == ig & 3
+          unsigned char* dst = buf + row * XROW + pswz(row, jq >> 1) + (jq & 1) * 8;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(hi[e][0], hi[e][1]);
+          if (NP >= 2) *reinterpret_cast<uint2*>(dst + PLN) = make_uint2(lo[e][0], lo[e][1]);
+        }
+      }
+    };
     auto jt = [&](int tile) { return jbeg + tile * BK; };   // tile index -> first column (jbeg % 32 == 0)
 #ifdef STEIN_STAMPS
     u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -696,9 +778,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
 #pragma unroll
     for (int u = 0; u < PD; ++u)
-      if (tile_at(0, u) < ntile) issue_loads(jt(tile_at(0, u)), rd[u]);
+      if (tile_at(0, u) < ntile) request(jt(tile_at(0, u)), 0 < ntr, rd[u]);
     // stage st: turn the registers of its tiles into LDS data (slot u <- tile_at(st, u)), then request the next stage's
     auto produce_stage = [&](int st, unsigned char* buf) {
+      const bool tr_now = st < ntr, tr_next = st + 1 < ntr;   // workgroup-uniform
 #pragma unroll
       for (int u = 0; u < FS_KT; ++u) {
         const int tile_u = tile_at(st, u), next_u = tile_at(st + 1, u);
@@ -706,12 +789,13 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
           STAMP(0);
           wait_loads(st * FS_KT + u, rd[u % PD]);   // (tiles are requested in visit order: position = st * FS_KT + u)
           STAMP(1);   // diagnostic builds: how long the producer waited for this tile's D loads
-          produce(jt(tile_u), buf + u * FS_KTB, rd[u % PD]);
+          if (tr_now) produce_tr(buf + u * FS_KTB, rd[u % PD]);
+          else produce(jt(tile_u), buf + u * FS_KTB, rd[u % PD]);
         }
 #if defined(STEIN_ABL_P_HALFLOAD)   // (ablation build: only the workgroups of column block 0 stream D)
-        if (cb == 0 && next_u < ntile) issue_loads(jt(next_u), rd[u % PD]);
+        if (cb == 0 && next_u < ntile) request(jt(next_u), tr_next, rd[u % PD]);
 #elif !defined(STEIN_ABL_P_NOLOAD)   // (ablation build: the producers re-use the first tiles' registers)
-        if (next_u < ntile) issue_loads(jt(next_u), rd[u % PD]);
+        if (next_u < ntile) request(jt(next_u), tr_next, rd[u % PD]);
 #endif
       }
     };
@@ -736,7 +820,25 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     }
     if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[1] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[2]); }
 #endif
-    if (cb == 0) {   // rowsum: the 8 threads of a row are 8 consecutive lanes
+    if (up) {
+      // natural tiles: rows lr + 32 p, the 8 threads of a row are 8 consecutive lanes; mirrored tiles: rows 4 ig + e, the 8
+      // threads of a row are the lanes jq = 0..7 (lane bits 3..5).  The two row sets meet in LDS (the stage buffers are
+      // dead: every wave is past the loop's last barrier; the matrix waves take the same extra barrier) and are added in a
+      // fixed order.
+      float* red = reinterpret_cast<float*>(smem);   // [128] natural sums | [128] mirrored sums
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float a = rs[p < PR ? p : 0], b = rst[p];
+        a += __shfl_xor(a, 1); b += __shfl_xor(b, 8);
+        a += __shfl_xor(a, 2); b += __shfl_xor(b, 16);
+        a += __shfl_xor(a, 4); b += __shfl_xor(b, 32);
+        if ((pt & 7) == 0) red[lr + 32 * p] = a;
+        if (jq == 0) red[128 + 4 * ig + p] = b;
+      }
+      __syncthreads();
+      const int row = i0 + pt;
+      if (cb == 0 && pt < 128 && row < n_local) RS[(size_t)z * n_local + row] = (red[pt] + red[128 + pt]) * sc[4 * dc + 2];
+    } else if (cb == 0) {   // rowsum: the 8 threads of a row are 8 consecutive lanes
 #pragma unroll
       for (int p = 0; p < PR; ++p) {
         float sum = rs[p];
@@ -886,6 +988,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       atomicAdd(&g_stamps[6], st_acc[0]);   // time spent waiting for the B fragments at the top of a tile
     }
 #endif
+    if (up) __syncthreads();   // the producers' row-sum exchange (same barrier count in both roles)
     if (g >= 2 * gblocks) return;   // (an odd block count leaves the last workgroup's upper waves without columns)
     float* __restrict__ Oz = (g < gblocks ? OG : OT) + (size_t)z * n_local * d;
     const int cbase = (g < gblocks ? g : g - gblocks) * BN + wcol + l15;
@@ -993,15 +1096,15 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
 
 int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L, int dtype,
                               const float* h2_dev, float* OG, float* OT, float* RS, int64_t n, int64_t d,
-                              int64_t n_local, hipStream_t stream) {
+                              int64_t n_local, hipStream_t stream, bool upper) {
   const u16* Tt3 = reinterpret_cast<const u16*>(planes + L.x3_tt3);
   const u16* Gt3 = reinterpret_cast<const u16*>(planes + L.x3_gt3);
   const float* sc = reinterpret_cast<const float*>(planes + L.x3_sc);
   // 64-row x 512-column workgroups when the 128-column blocks of [G | theta] fill them (an even block count per matrix)
-  const bool wide = L.phi_wide != 0;
+  const bool wide = L.phi_wide != 0 && !upper;   // the 64-row form has no mirrored-tile path
   const long tm = wide ? (n_local + 63) / 64 : L.tiles_m, cbk = wide ? L.cblocks / 2 : L.cblocks;
   const long nblk = tm * cbk * L.split;
-#define X3_PHI(NP, RB) hipLaunchKernelGGL((k_phi_x3fs<NP, RB>), dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3, (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)tm, (int)cbk, (int)L.cblocks, (int)L.split, (int)L.jchunk, sc, (int)L.x3_dc)
+#define X3_PHI(NP, RB) hipLaunchKernelGGL((k_phi_x3fs<NP, RB>), dim3((unsigned)nblk), dim3(FS_THREADS), 0, stream, dist, (long)ld_dist, Gt3, Tt3, (long)(L.x3_nk / 32), h2_dev, OG, OT, RS, (int)n, (int)d, (int)n_local, (int)tm, (int)cbk, (int)L.cblocks, (int)L.split, (int)L.jchunk, sc, (int)L.x3_dc, upper ? 1 : 0)
   switch (split_kind(dtype) * 2 + (wide ? 1 : 0)) {
     case 2: X3_PHI(1, 8); break;
     case 3: X3_PHI(1, 4); break;

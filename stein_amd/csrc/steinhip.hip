@@ -765,13 +765,17 @@ __device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, Sp
 // ------------------------------------------------------------------------------------------------
 // k_kernel_matrix: optional K output, K = exp(-D / h2 / 2)
 // ------------------------------------------------------------------------------------------------
+// upper: D holds only the 128 x 128 tiles on and above the diagonal (the split path's symmetric distance pass); an entry
+// of a tile below it is read from its mirror image
 __global__ __launch_bounds__(256) void k_kernel_matrix(const float* __restrict__ D, long ldD, int n_local, int n,
-                                                       const float* __restrict__ h2p, float* __restrict__ K, long ldK) {
+                                                       const float* __restrict__ h2p, float* __restrict__ K, long ldK,
+                                                       int upper) {
   const float h2 = *h2p;
   const long total = (long)n_local * n;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long row = e / n, col = e - row * n;
-    K[row * ldK + col] = expf(-D[d_index(row, col, ldD >> 5)] / h2 / 2.f);
+    const bool swap = upper && (col >> 7) < (row >> 7);
+    K[row * ldK + col] = expf(-D[d_index(swap ? col : row, swap ? row : col, ldD >> 5)] / h2 / 2.f);
   }
 }
 
@@ -1108,7 +1112,9 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
     const double eff = rounds / ceil(rounds) - 0.004 * (double)(s - 1);
     if (eff > best + 1e-9) { best = eff; split = s; }
   }
-  const int64_t tiles_per = (jt + split - 1) / split;
+  int64_t tiles_per = (jt + split - 1) / split;
+  if (x3) tiles_per = (tiles_per + 3) / 4 * 4;   // a j range of the split kernel starts on a multiple of 128 columns (its
+                                                 // pipeline stages then never straddle a row tile's diagonal block)
   L->jchunk = tiles_per * BK;
   split = (jt + tiles_per - 1) / tiles_per;  // drop empty tails
   L->split = split;
@@ -1373,11 +1379,14 @@ extern "C" int stein_spec_update(void* select_state, void* stream) {
 }
 
 extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n,
-                                   const float* h2_dev, float* K_out, int64_t ld_K, void* stream) {
+                                   const float* h2_dev, float* K_out, int64_t ld_K, int dist_flags, void* stream) {
   if (!dist || !h2_dev || !K_out) return fail(STEIN_E_BADARG, "NULL pointer");
   if (ld_dist < n || ld_K < n || n_local < 1) return fail(STEIN_E_SHAPE, "bad shape");
+  if (dist_flags & ~(STEIN_STAGE_SYMMETRIC | STEIN_STAGE_UPPER)) return fail(STEIN_E_BADARG, "unknown distance flags 0x%x", dist_flags);
+  if ((dist_flags & STEIN_STAGE_UPPER) && n_local != n) return fail(STEIN_E_BADARG, "STEIN_STAGE_UPPER needs the whole matrix");
   hipLaunchKernelGGL(k_kernel_matrix, dim3(grid_for((long)n_local * n, 4096)), dim3(256), 0, (hipStream_t)stream,
-                     dist, (long)ld_dist, (int)n_local, (int)n, h2_dev, K_out, (long)ld_K);
+                     dist, (long)ld_dist, (int)n_local, (int)n, h2_dev, K_out, (long)ld_K,
+                     (dist_flags & STEIN_STAGE_UPPER) ? 1 : 0);
   LAUNCH_CHECK("k_kernel_matrix");
   return STEIN_OK;
 }
@@ -1385,7 +1394,11 @@ extern "C" int stein_kernel_matrix(const float* dist, int64_t ld_dist, int64_t n
 extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const void* theta_all,
                                       const void* score_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
                                       int dtype, const float* h2_dev, const void* x3_planes, void* workspace,
-                                      size_t ws_bytes, void* stream) {
+                                      size_t ws_bytes, int dist_flags, void* stream) {
+  if (dist_flags & ~(STEIN_STAGE_SYMMETRIC | STEIN_STAGE_UPPER)) return fail(STEIN_E_BADARG, "unknown distance flags 0x%x", dist_flags);
+  const bool upper = (dist_flags & STEIN_STAGE_UPPER) != 0;
+  if (upper && (!x3_planes || row0 != 0 || n_local != n))
+    return fail(STEIN_E_BADARG, "STEIN_STAGE_UPPER: only the split path's symmetric distance pass stores the upper triangle alone");
   if (!dist || (!x3_planes && (!theta_all || !score_all)) || !h2_dev || !workspace)
     return fail(STEIN_E_BADARG, "NULL pointer");
   if (dtype != STEIN_F32 && !(dtype == STEIN_BF16 && x3_planes))
@@ -1406,7 +1419,7 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
   const long nblk = (long)L.tiles_m * 2 * L.cblocks * L.split;
   if (nblk > 0x7fffffffl) return fail(STEIN_E_SHAPE, "too many tiles");
   if (x3_planes)
-    return stein_x3_contract_partial(dist, ld_dist, (const char*)x3_planes, L, dtype, h2_dev, OG, OT, RS, n, d, n_local, s);
+    return stein_x3_contract_partial(dist, ld_dist, (const char*)x3_planes, L, dtype, h2_dev, OG, OT, RS, n, d, n_local, s, upper);
   const bool vec = (d % 4 == 0) && (((uintptr_t)T & 15) == 0) && (((uintptr_t)G & 15) == 0);
   if (vec)
     hipLaunchKernelGGL(k_phi_partial<true>, dim3((unsigned)nblk), dim3(NTHREADS), 0, s, dist, (long)ld_dist, G, T,
@@ -1456,9 +1469,10 @@ extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d
 extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
                                      int64_t n, int64_t d, int64_t row0, int64_t n_local, int dtype,
                                      const float* h2_dev, float* phi_local, double* sqnorm_out, float* dK_out,
-                                     const void* x3_planes, void* workspace, size_t ws_bytes, void* stream) {
+                                     const void* x3_planes, void* workspace, size_t ws_bytes, int dist_flags,
+                                     void* stream) {
   int rc = stein_contract_partial(dist, ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, x3_planes,
-                                  workspace, ws_bytes, stream);
+                                  workspace, ws_bytes, dist_flags, stream);
   if (rc) return rc;
   return stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
                                ws_bytes, x3_planes ? STEIN_FLAG_X3 : 0, stream);
@@ -1560,7 +1574,7 @@ extern "C" int stein_rank_finish(const void* theta_all, const void* score_all, i
   if (tev)
     for (int k = 0; k <= STEIN_T_CONTRACT; ++k) HIP_TRY(hipEventRecord(tev[k], (hipStream_t)stream));
   if ((rc = stein_contract_partial(v.D, v.L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, v.planes,
-                                   workspace, ws_bytes, stream)))
+                                   workspace, ws_bytes, 0, stream)))
     return rc;
   if (tev) HIP_TRY(hipEventRecord(tev[STEIN_T_FINISH], (hipStream_t)stream));
   rc = stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
@@ -1689,10 +1703,16 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit,
                              true, lv == STEIN_HIST_LEVELS - 1 ? fin : HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f})))
       return rc;
-  if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, stream))) return rc;
+  // the split path's symmetric distance pass stores only the tiles on and above the diagonal
+#ifdef STEIN_NO_UPPER   // (A/B build: the full mirrored image of round 1)
+  const int df = STEIN_STAGE_SYMMETRIC;
+#else
+  const int df = planes ? (STEIN_STAGE_SYMMETRIC | STEIN_STAGE_UPPER) : STEIN_STAGE_SYMMETRIC;
+#endif
+  if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, df, stream))) return rc;
   STEIN_TSTAMP(STEIN_T_CONTRACT);
   if ((rc = stein_contract_partial(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, planes,
-                                   workspace, ws_bytes, stream)))
+                                   workspace, ws_bytes, df, stream)))
     return rc;
   STEIN_TSTAMP(STEIN_T_FINISH);
   if ((rc = stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_out, phi_local, sqnorm_out, dK_out, workspace,

@@ -45,11 +45,18 @@ def _stream(t):
                        "stein_amd has no CPU path." % t.device)
 
 
-def untile_distances(block, n_local, n):
-    """tile-major distance image (flat [rows_padded, ld] view, tiles of [128][32]) -> row-major [n_local, n] copy"""
+def untile_distances(block, n_local, n, upper=False):
+    """tile-major distance image (flat [rows_padded, ld] view, tiles of [128][32]) -> row-major [n_local, n] copy.
+    upper: the image holds only the 128 x 128 tiles on and above the diagonal of a symmetric matrix (the split path's
+    symmetric distance pass); the others are filled in from their mirror images."""
     rows, ld = block.shape
     t = block.reshape(rows // 128, ld // 32, 128, 32).permute(0, 2, 1, 3).reshape(rows, ld)
-    return t[:n_local, :n].contiguous()
+    m = t[:n_local, :n].contiguous()
+    if upper:
+        bi = torch.arange(n_local, device=m.device) // 128
+        lower = bi[:, None] > bi[None, :]              # entries of tiles strictly below the block diagonal
+        m = torch.where(lower, m.T, m)
+    return m
 
 
 def tile_distances(matrix, ld):
@@ -112,12 +119,14 @@ class HipStages:
     def median_resolve(self, hist, level, n, sel, h2, median):
         _lib.call_on(hist.device, "stein_median_resolve", _ptr(hist), level, n, _ptr(sel), _ptr(h2), _ptr(median), _stream(hist))
 
-    def kernel_matrix(self, D, ld, n_local, n, h2, K):
-        _lib.call_on(D.device, "stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0), _stream(D))
+    # upper: D is what distance_block(symmetric=True, planes=...) leaves -- only the tiles on and above the diagonal
+    def kernel_matrix(self, D, ld, n_local, n, h2, K, upper=False):
+        _lib.call_on(D.device, "stein_kernel_matrix", _ptr(D), ld, n_local, n, _ptr(h2), _ptr(K), K.stride(0),
+                     _lib.STAGE_UPPER if upper else 0, _stream(D))
 
-    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None):
+    def contract_partial(self, D, ld, T, G, n, d, row0, n_local, h2, ws, planes=None, upper=False):
         _lib.call_on(D.device, "stein_contract_partial", _ptr(D), ld, _ptr(T), _ptr(G), n, d, row0, n_local, _dt(T), _ptr(h2),
-                  _ptr(planes), _ptr(ws), ws.numel(), _stream(D))
+                  _ptr(planes), _ptr(ws), ws.numel(), _lib.STAGE_UPPER if upper else 0, _stream(D))
 
     def contract_finish(self, T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, flags=0):
         _lib.call_on(T.device, "stein_contract_finish", _ptr(T), n, d, row0, n_local, _dt(T), _ptr(h2), _ptr(phi),
@@ -163,8 +172,8 @@ class HipStages:
                      ctypes.byref(hit), _stream(T_all))
         return None if hit.value < 0 else bool(hit.value)
 
-    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None):
-        self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws, planes)
+    def kernel_contract(self, D, ld, T, G, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, planes=None, upper=False):
+        self.contract_partial(D, ld, T, G, n, d, row0, n_local, h2, ws, planes, upper)
         self.contract_finish(T, n, d, row0, n_local, h2, phi, sqnorm, dK, ws, _lib.FLAG_X3 if planes is not None else 0)
 
 
@@ -183,6 +192,8 @@ class SvgdEngine:
               segments.  "auto" (default): native on GPUs with the HIP stages when the group's backend is nccl (RCCL),
               torch otherwise.
     """
+
+    _full_distance_image = False   # set by scratch/ab.py for -DSTEIN_NO_UPPER builds (the mirrored image of round 1)
 
     def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True,
                  window=True, force_collectives=False, comm="auto"):
@@ -250,6 +261,7 @@ class SvgdEngine:
         if self.sharded:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
+        self.dist_upper = False      # the distance image holds only the tiles on and above the diagonal (set per step)
         self._flags_host = None      # page-locked landing place of the window's hit flag (HIP stages, window form)
         self._flags_event = None
         if comm not in ("auto", "native", "torch"):
@@ -302,8 +314,9 @@ class SvgdEngine:
         return self._section(_lib.WS_DIST, rows * self.ld_dist * 4, torch.float32).view(rows, self.ld_dist)
 
     def dist_matrix(self):
-        """Row-major [n_local, n] copy of the distance block (de-tiled; for inspection and tests)."""
-        return untile_distances(self.dist, self.n_local, self.n)
+        """Row-major [n_local, n] copy of the distance block (de-tiled; for inspection and tests).  After a single-rank
+        step on the split path only the tiles on and above the diagonal are stored; the rest is mirrored in here."""
+        return untile_distances(self.dist, self.n_local, self.n, upper=self.dist_upper)
 
     @property
     def hist(self):
@@ -446,6 +459,7 @@ class SvgdEngine:
         if not self.sharded and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
                         self.flags | (_lib.FLAG_TIMING if timing else 0))
+            self.dist_upper = self.x3
             return self.phi
         if self.sharded and mark is None and K_out is None and self._comm is not None:
             flags = ((self.flags & _lib.FLAG_X3) | (_lib.FLAG_RANK_WINDOW if self.dist_window else 0) |
@@ -488,14 +502,18 @@ class SvgdEngine:
                               planes=planes)
             mark("median")
             self._radix_levels(0)
+        upper = sym and planes is not None     # what the symmetric distance pass of the split path stores
+        if SvgdEngine._full_distance_image:     # A/B scripts against -DSTEIN_NO_UPPER builds of the library only
+            upper = False
+        self.dist_upper = upper
         if K_out is not None:
-            st.kernel_matrix(D, ld, nl, n, self.h2, K_out)
+            st.kernel_matrix(D, ld, nl, n, self.h2, K_out, upper)
         if gather_g is not None:
             gather_g.wait()            # the launching stream waits for the gathered score rows (the host does not)
             if planes is not None:
                 st.x3_prepare(None, G_all, n, d, planes)
         mark("contract")
-        st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws, planes)
+        st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws, planes, upper)
         mark("finish")
         st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws, self.flags)
         if self.sharded:

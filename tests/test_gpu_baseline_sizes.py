@@ -65,18 +65,36 @@ def fp64_rows(T, G, rows, h2):
     return D, (K @ Ga + dK) / T.shape[0]
 
 
-def dist_rows(block, rows, n):
-    """rows of the tile-major distance image [rows_padded, ld] (tiles of [128][32]) -> [len(rows), n]"""
+def dist_rows(block, rows, n, upper=False):
+    """rows of the tile-major distance image [rows_padded, ld] (tiles of [128][32]) -> [len(rows), n].
+    upper: only the tiles on and above the diagonal are stored; the part of a row left of its diagonal block is the
+    corresponding COLUMN of the stored tiles above it."""
     rp, ld = block.shape
     v = block.view(rp // 128, ld // 32, 128, 32)
     idx = torch.as_tensor(rows, device=block.device)
-    return v[idx // 128, :, idx % 128, :].reshape(len(rows), ld)[:, :n]
+    out = v[idx // 128, :, idx % 128, :].reshape(len(rows), ld)[:, :n].clone()
+    if upper:
+        for k, i in enumerate(rows):
+            lo = (i // 128) * 128                      # columns [0, lo) come from D[j][i], j < lo
+            if lo:
+                out[k, :lo] = v[:lo // 128, i // 32, :, i % 32].reshape(-1)
+    return out
 
 
-def count_less_leq(images, v, chunk=1 << 28):
-    """(#entries < v, #entries <= v) over flat fp32 images (no padding: n % 128 == 0 here), in bounded chunks"""
+def count_less_leq(images, v, chunk=1 << 28, upper=False):
+    """(#entries < v, #entries <= v) over tile-major fp32 images (no padding: n % 128 == 0 here), in bounded pieces.
+    upper: the image is the single-rank split path's -- only the 128 x 128 tiles on and above the diagonal are stored;
+    an entry of a tile above the diagonal also stands for its mirror image (weight 2), the diagonal tiles are complete."""
     less = leq = 0
     for img in images:
+        if upper:
+            rp, ld = img.shape
+            v4 = img.view(rp // 128, ld // 32, 128, 32)            # [row block][column tile][128][32]
+            for I in range(rp // 128):
+                dg, off = v4[I, 4 * I:4 * I + 4], v4[I, 4 * I + 4:]
+                less += int((dg < v).sum().item()) + 2 * int((off < v).sum().item())
+                leq += int((dg <= v).sum().item()) + 2 * int((off <= v).sum().item())
+            continue
         flat = img.reshape(-1)
         for o in range(0, flat.numel(), chunk):
             c = flat[o:o + chunk]
@@ -85,13 +103,13 @@ def count_less_leq(images, v, chunk=1 << 28):
     return less, leq
 
 
-def check_exact_bandwidth(images, state_f32, n, h2_reported):
+def check_exact_bandwidth(images, state_f32, n, h2_reported, upper=False):
     """counting proof + bit-exact bandwidth arithmetic; returns h2"""
     total = n * n
     med, h2, lo, hi = (state_f32[k].item() for k in (8, 9, 10, 11))
     k_lo = total // 2 - 1 if total % 2 == 0 else total // 2
     for v, k in ((lo, k_lo), (hi, total // 2)):
-        less, leq = count_less_leq(images, v)
+        less, leq = count_less_leq(images, v, upper=upper)
         assert less <= k < leq, ("not the order statistic", v, k, less, leq)
     assert med == np.float32(0.5) * (np.float32(lo) + np.float32(hi))            # n^2 even for every config here
     bw = np.sqrt(np.float32(med) / np.float32(math.log(n)))
@@ -123,9 +141,9 @@ def run_fused(cuda, n, d, x3, label, dtype=torch.float32, tol=TOL, d_tol=4e-6):
     phi = eng.compute_phi(T.to(dtype), G.to(dtype))
     torch.cuda.synchronize()
     assert bool(torch.isfinite(phi).all())
-    h2 = check_exact_bandwidth([eng.dist], eng.select_state.view(torch.float32), n, eng.h2.item())
+    h2 = check_exact_bandwidth([eng.dist], eng.select_state.view(torch.float32), n, eng.h2.item(), upper=eng.dist_upper)
     rows = sample_rows(n, seed=n + d)
-    rel = check_rows(phi[rows], dist_rows(eng.dist, rows, n), T, G, rows, h2, label, tol, d_tol)
+    rel = check_rows(phi[rows], dist_rows(eng.dist, rows, n, eng.dist_upper), T, G, rows, h2, label, tol, d_tol)
     # |phi|^2 of the whole matrix, reduced on the device
     assert abs(eng.sqnorm.item() - (phi.double() ** 2).sum().item()) <= 1e-9 * eng.sqnorm.item()
     return eng, T, G, phi, h2, rel
