@@ -153,3 +153,20 @@ def test_c_host_example_builds_as_plain_c11(tmp_path):
     import __graft_entry__ as ge
     exe = ge.build_c_host(str(tmp_path / "svgd_steps"))
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+def test_upper_image_flag_is_refused_where_no_upper_image_can_exist():
+    """STEIN_STAGE_UPPER (the distance image holds only the tiles on / above the diagonal) is what the split path's
+    symmetric single-rank distance pass leaves; a row block or the fp32-MFMA path never has it -- refused before any launch."""
+    lib = _lib.load()
+    fake = (ctypes.c_ubyte * 64)()
+    f = ctypes.cast(fake, ctypes.c_void_p)
+    tot, offs, extra = _lib.workspace_layout(128, 256, 8, _lib.F32, _lib.FLAG_X3 | _lib.FLAG_TILED)
+    ld = extra[_lib.WSX_LD_DIST]
+    # a row block (row0 = 128 of n = 256)
+    assert lib.stein_contract_partial(f, ld, f, f, 256, 8, 128, 128, _lib.F32, f, f, f, tot, _lib.STAGE_UPPER, None) == _lib.E_BADARG
+    assert b"STEIN_STAGE_UPPER" in lib.stein_last_error()
+    # the fp32-MFMA path (no operand planes)
+    assert lib.stein_contract_partial(f, ld, f, f, 256, 8, 0, 256, _lib.F32, f, None, f, 1 << 40, _lib.STAGE_UPPER, None) == _lib.E_BADARG
+    # an unknown distance flag
+    assert lib.stein_contract_partial(f, ld, f, f, 256, 8, 0, 256, _lib.F32, f, f, f, 1 << 40, 64, None) == _lib.E_BADARG
