@@ -28,10 +28,23 @@ def mark(label):        # the staged calls: reset the counters right before the 
         acc[:] += np.array(list(buf), dtype=np.float64); cacc[:] += np.array(list(clk), dtype=np.float64)
         wacc[:] += np.array(list(wv), dtype=np.float64)
 reps = 8
+lib.stein_debug_wg.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+wgbuf = (ctypes.c_uint64 * 3072)()
+kev = []
+def mark2(label):
+    mark(label)
+    if label in ("contract", "finish"):
+        e = torch.cuda.Event(enable_timing=True); e.record(); kev.append(e)
+kms = 0.0
 for _ in range(reps):
     for _ in range(30): eng.compute_phi(T, G)          # keep the chip loaded between the measured launches
-    eng.compute_phi(T, G, mark=mark)
+    kev.clear()
+    eng.compute_phi(T, G, mark=mark2)
+    torch.cuda.synchronize()
+    kms += kev[0].elapsed_time(kev[1])
+    lib.stein_debug_wg(wgbuf, 0)
 torch.cuda.synchronize()
+print("contraction launch, event-timed (this stamped build): %.4f ms" % (kms / reps))
 v = acc; clk = cacc
 nb = v[7]
 jt = (n + 31) // 32
@@ -40,8 +53,19 @@ print("workgroups", nb / reps, "split", eng.split, "k tiles per workgroup", jt /
 for k, nm in enumerate(names):
     print("%-17s %8.1f shader cycles per k tile" % (nm, v[k] / nb / (jt / eng.split)))
 if clk[1]:
+    print("main loop of a matrix wave (first stage barrier .. last): %.4f ms real time per workgroup" % (clk[1] / nb * 1e-5))
     print("in-kernel clock of the contraction (delta s_memtime / delta s_memrealtime x 100 MHz): %.3f GHz" % (clk[0] / clk[1] * 0.1))
 per = nb * (jt / eng.split)
 print("per wave (cycles per k tile): work | at the stage barrier")
 for w in range(12):
     print("  wave %2d (%s): %7.1f | %7.1f" % (w, "producer" if w < 4 else "matrix", wacc[2 * w] / per, wacc[2 * w + 1] / per))
+w = np.array(list(wgbuf), dtype=np.float64).reshape(1024, 3)
+w = w[w[:, 2] > 0]
+t0 = w[:, 0].min()
+ent, beg, end = (w[:, 0] - t0) * 1e-2, (w[:, 1] - t0) * 1e-2, (w[:, 2] - t0) * 1e-2      # microseconds
+print("last launch, %d workgroups (us from the first workgroup's entry): entry %.1f..%.1f  main loop starts %.1f..%.1f (mean %.1f)  ends %.1f..%.1f (mean %.1f)"
+      % (len(w), ent.min(), ent.max(), beg.min(), beg.max(), beg.mean(), end.min(), end.max(), end.mean()))
+dur = end - beg
+print("main-loop duration per workgroup: min %.1f  mean %.1f  max %.1f us; percentiles 10/50/90/99: %s" % (dur.min(), dur.mean(), dur.max(), np.percentile(dur, [10, 50, 90, 99]).round(1)))
+xcd = np.arange(len(w)) % 8
+for x in range(8): print("  XCD %d: mean main loop %.1f us, mean end %.1f" % (x, dur[xcd == x].mean(), end[xcd == x].mean()))

@@ -78,6 +78,12 @@ extern "C" int stein_debug_waves(u64* host_out, int reset) {
   if (reset) { u64 z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
+__device__ u64 g_wg[3 * 1024];   // contraction, per workgroup: real-time ticks (100 MHz) at kernel entry, main-loop start, main-loop end
+extern "C" int stein_debug_wg(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg), sizeof(u64) * 3 * 1024) != hipSuccess) return -1;
+  if (reset) { static u64 z[3 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 __device__ u64 g_clock[2];   // sums over the sampled waves of (shader-clock ticks, 100 MHz real-time ticks) inside the contraction's main loop
 extern "C" int stein_debug_clock(u64* host_out, int reset) {
   if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock), sizeof(u64) * 2) != hipSuccess) return -1;
@@ -855,6 +861,9 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // than on 32x32x16 at the same cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7).
     const int ct = t - 256, lane = ct & 63, cw = ct >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
+#ifdef STEIN_STAMPS
+    if (t == 256 && blockIdx.x < 1024) { g_wg[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#endif
     // this wave's 128-column block of [G | theta] and its CJ 16-column blocks inside it
     const int g = RB == 8 ? 2 * cb + (cw >> 2) : 4 * cb + (cw >> 1);
     const int wcol = RB == 8 ? (cw & 3) * 32 : (cw & 1) * 64;   // first column inside the block (16 CJ columns)
@@ -932,6 +941,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     u64 st_last = __builtin_amdgcn_s_memtime();
     const u64 clk0 = st_last, rt0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (t == 256 && blockIdx.x < 1024) g_wg[3 * blockIdx.x + 1] = rt0;
 #endif
     for (int st = 0; st < nstage; ++st) {
       STAMP(5);
@@ -979,6 +989,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       __builtin_amdgcn_s_waitcnt(0xC07F);
       atomicAdd(&g_clock[0], clk1 - clk0);
       atomicAdd(&g_clock[1], rt1 - rt0);
+      if (blockIdx.x < 1024) g_wg[3 * blockIdx.x + 2] = rt1;
     }
     if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[3] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[4]); }
     if (t == 256)
