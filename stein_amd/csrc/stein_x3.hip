@@ -16,9 +16,11 @@
 //
 //   k_colmax, k_make_scales   column maxima -> power-of-two scales (KIND 2; all ones otherwise)
 //   k_split         theta, score -> 16-bit operand tiles ("planes", layout below)
-//   k_distance_x3   S = T T^T from the planes; shares the fp32 kernel's epilogue (D, mirror, level-0 histogram)
-//   k_phi_x3fs      warp-specialised contraction: producer waves build P = exp2(c D) (split on the fly) in LDS,
-//                   consumer waves stream the V fragments from L2 and issue the MFMAs
+//   k_distance_x3   S = T T^T from the planes; shares the fp32 kernel's epilogue (D, level-0 histogram or window counting).
+//                   Single rank: only the 128 x 128 tiles on and above the diagonal are computed AND stored
+//   k_phi_x3fs      warp-specialised contraction: producer waves build P = exp2(c D) (split on the fly) in LDS -- a k tile
+//                   left of the row tile's diagonal block from its mirror image D[j][i] --, consumer waves stream the V
+//                   fragments from L2 and issue the MFMAs
 //
 // Both GEMMs are "row x row" products (C[i][c] = sum_k A[i][k] B[c][k]) with k contiguous for both operands.
 //
