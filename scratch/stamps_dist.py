@@ -12,6 +12,8 @@ eng = SvgdEngine(n, d, device="cuda", x3=True, small=False)
 st = eng.stages
 for _ in range(30): eng.compute_phi(T, G)
 lib.stein_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+lib.stein_debug_xcd.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+xb = (ctypes.c_uint64 * 16)()
 buf = (ctypes.c_uint64 * 8)()
 sel, spec, hist = eng.select_state, eng.spec_section, eng.hist
 state = sel.clone()
@@ -24,7 +26,7 @@ for sym in (True, False):
             sel.copy_(state)
             if mode == "window": st.spec_begin(hist, sel, spec, n * n)
             else: st.median_begin(hist, sel, n * n)
-            torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1)
+            torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 1); lib.stein_debug_xcd(xb, 1)
             fl = _lib.STAGE_SYMMETRIC if sym else 0
             e0.record()
             if mode == "window":
@@ -32,8 +34,11 @@ for sym in (True, False):
                           _ptr(hist[0]), _ptr(eng.planes), fl, _ptr(sel), _ptr(spec), _stream(T))
             else:
                 st.distance_block(T, eng.rownorm, n, d, 0, n, eng.dist, eng.ld_dist, hist0=None, symmetric=sym, planes=eng.planes)
-            e1.record(); torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0)
+            e1.record(); torch.cuda.synchronize(); lib.stein_debug_stamps(buf, 0); lib.stein_debug_xcd(xb, 0)
             acc += np.array(list(buf), dtype=np.float64); ms += e0.elapsed_time(e1)
+        xv = np.array(list(xb), dtype=np.float64)
+        t0 = xv[8:].min()
+        print("      last launch, per XCD: first workgroup end %s us, last workgroup end %s us" % (((xv[8:] - t0) * 1e-2).round(1).tolist(), ((xv[:8] - t0) * 1e-2).round(1).tolist()), flush=True)
         nb = acc[7]
         tot = acc[:4].sum() / nb
         print("%-5s %-7s %.3f ms  wgs %6d | per workgroup (cycles): wait loads+LDS store %7.0f  barriers %7.0f  issue+MFMA %7.0f  epilogue %7.0f  total %7.0f"

@@ -86,6 +86,12 @@ extern "C" int stein_debug_wg(u64* host_out, int reset) {
   if (reset) { static u64 z[3 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
+__device__ u64 g_xcd[16];   // distance pass: [x] latest workgroup end on XCD x (blockIdx % 8), [8 + x] earliest end; 100 MHz ticks
+extern "C" int stein_debug_xcd(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xcd), sizeof(u64) * 16) != hipSuccess) return -1;
+  if (reset) { u64 z[16]; for (int i = 0; i < 16; ++i) z[i] = i < 8 ? 0ull : ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_xcd), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 __device__ u64 g_clock[2];   // sums over the sampled waves of (shader-clock ticks, 100 MHz real-time ticks) inside the contraction's main loop
 extern "C" int stein_debug_clock(u64* host_out, int reset) {
   if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock), sizeof(u64) * 2) != hipSuccess) return -1;
@@ -491,6 +497,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
   if (t == 0) {
     for (int k = 0; k < 4; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
     atomicAdd(&g_stamps[7], 1ull);
+    const u64 rt = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    atomicMax(reinterpret_cast<unsigned long long*>(&g_xcd[blockIdx.x & 7]), (unsigned long long)rt);
+    atomicMin(reinterpret_cast<unsigned long long*>(&g_xcd[8 + (blockIdx.x & 7)]), (unsigned long long)rt);
   }
 #endif
 }
