@@ -166,3 +166,40 @@ def test_seeded_initial_particles_are_distinct_across_ranks_and_match_one_rank(t
                        device="cpu", seed=11, dtype=torch.float64)
     assert np.array_equal(both, one.theta_matrix.numpy())                # the sharded draw IS the single-rank draw
     assert abs(both.std() - 0.01) < 0.004                                # N(0, 0.01^2), abstract_stein_sampler.py:69-74
+
+
+def _worker_comm_arg(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stein_amd import _lib
+        from stein_amd.engine import SvgdEngine
+        from oracle.staged_model import NumpyStages
+        st = NumpyStages(_lib.workspace_layout)
+        eng = SvgdEngine(64, 4, device="cpu", group=dist.group.WORLD, stages=st)          # auto -> torch on gloo / CPU
+        msg = ""
+        try:
+            SvgdEngine(64, 4, device="cpu", group=dist.group.WORLD, stages=st, comm="native")
+        except ValueError as e:
+            msg = str(e)
+        bad = ""
+        try:
+            SvgdEngine(64, 4, device="cpu", group=dist.group.WORLD, stages=st, comm="mpi")
+        except ValueError as e:
+            bad = str(e)
+        eng.close(); eng.close()                                                            # idempotent, no communicator
+        np.save(os.path.join(out_dir, "comm%d.npy" % rank), np.array([eng.comm, msg, bad]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_argument_is_validated(tmp_path):
+    """comm='auto' falls back to torch.distributed collectives off the GPU / off RCCL; comm='native' there is an error
+    (the library's communicator needs HIP tensors, the HIP stages and an nccl group), as is an unknown value."""
+    mp.spawn(_worker_comm_arg, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        comm, msg, bad = np.load(os.path.join(str(tmp_path), "comm%d.npy" % r))
+        assert comm == "torch"
+        assert "comm='native' needs" in msg
+        assert "comm must be" in bad
