@@ -446,11 +446,20 @@ def main():
                                                            2048 if key == "c4" else ro["n"])
             del ro
         out["other_configs"] = others
+    # the commit the working tree was at: from git where there is one, else from the stamp build() leaves beside the library
+    # (the GPU boxes get a snapshot without .git)
+    commit = None
     try:
-        out["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
-                                       text=True, timeout=5).stdout.strip() or None
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        commit = r.stdout.strip() or None if r.returncode == 0 else None
     except Exception:
-        out["commit"] = None
+        commit = None
+    if commit is None:
+        try:
+            commit = open(os.path.join(ROOT, "stein_amd", ".build_commit")).read().strip() or None
+        except OSError:
+            commit = None
+    out["commit"] = commit
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
