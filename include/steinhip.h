@@ -54,8 +54,10 @@ enum {
                             tiled kernels then also leave D, the histograms and the planes in the workspace */
   STEIN_FLAG_NO_WINDOW = 16, /* stein_svgd_phi only: never grant the speculative median window, i.e. run the radix-select
                                 passes over D on every call (same result; what a window miss costs, for measurements) */
-  STEIN_FLAG_RANK_WINDOW = 32 /* stein_rank_* only: this step uses the cross-rank speculative window (tally / pick) instead
-                                 of the radix-select histograms */
+  STEIN_FLAG_RANK_WINDOW = 32, /* stein_rank_* only: this step uses the cross-rank speculative window (tally / pick) instead
+                                  of the radix-select histograms */
+  STEIN_FLAG_TILE_DISTANCE = 64 /* stein_svgd_phi only: run the distance pass with the per-tile kernel even where the
+                                   panel-resident form (STEIN_STAGE_TILES below) would be taken; for A/B measurements */
 };
 /* flags for the staged distance / histogram calls */
 enum {
@@ -64,10 +66,16 @@ enum {
                                 (x3_planes = NULL) the distance pass stores each off-diagonal tile twice (mirrored): a
                                 full image.  On the split path it stores ONLY the 128 x 128 tiles on and above the
                                 diagonal; pass STEIN_STAGE_UPPER with that image to its readers.  Results are identical. */
-  STEIN_STAGE_UPPER = 2      /* readers of a distance image (stein_contract_partial, stein_kernel_contract,
+  STEIN_STAGE_UPPER = 2,     /* readers of a distance image (stein_contract_partial, stein_kernel_contract,
                                 stein_kernel_matrix): the image holds only the tiles on and above the diagonal of the
                                 whole symmetric matrix, as stein_distance_block(STEIN_STAGE_SYMMETRIC) with x3_planes
                                 leaves it; entries of the other tiles are read from their mirror images */
+  STEIN_STAGE_TILES = 4,     /* stein_distance_block*: always the per-tile kernel (one 128 x 128 tile per workgroup).  Without
+                                it, large blocks whose operand panel fits LDS (n, n_local, row0 multiples of 128; d <= 256
+                                for fp32 inputs; split path) take the panel-resident kernel (stein_amd/csrc/stein_dpanel.hip):
+                                the same formula, entries may differ from the per-tile kernel's in the last bit */
+  STEIN_STAGE_PANEL = 8      /* stein_distance_block*: take the panel-resident kernel whenever its restrictions hold, however
+                                small the block (tests) */
 };
 
 /* Workspace sections reported by stein_workspace_layout (byte offsets into the workspace). */

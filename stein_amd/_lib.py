@@ -20,11 +20,14 @@ WSX_N = 4
 HIST_BINS, HIST_LEVELS = 2048, 3
 STAGE_SYMMETRIC = 1
 STAGE_UPPER = 2
+STAGE_TILES = 4     # distance pass: always the per-tile kernel
+STAGE_PANEL = 8     # distance pass: the panel-resident kernel whenever its restrictions hold
 FLAG_X3 = 1
 FLAG_TIMING = 4
 FLAG_TILED = 8
 FLAG_NO_WINDOW = 16
 FLAG_RANK_WINDOW = 32
+FLAG_TILE_DISTANCE = 64
 GLM_LINEAR, GLM_LOGISTIC = 0, 1
 SPEC_TABLE_WORDS = 65544          # uint64 words of the rank-summed window table ...
 SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC section (slots + entry buffer)

@@ -28,11 +28,12 @@
 // them used; the third is a leftover of the three-term split) and tiles are stored tile-major:  tile(rb, kt) at ((rb * ntk + kt) * 3 + plane) * 4096 elements.
 // One wave-wide 16-byte-per-lane load therefore covers 1 KB of consecutive memory (row-major planes made every
 // 64-byte row piece its own cache-line visit: the producers spent 2900 cycles per k tile issuing loads).
-//   T3   rows = particles, k = parameters   (distance operands; rows of a tile may straddle two row blocks when a
-//        rank's row0 is not a multiple of 128, so this image is NOT pre-swizzled)
-//   Vt3  rows = parameters, k = particles   (theta^T and score^T: the contraction's B operand; never staged in LDS:
-//        each plane of a tile is stored in MFMA fragment order [row / 16][chunk][row % 16][8] (vfrag_offset), so the
-//        B fragment of a 16-column block is ONE coalesced 1 KB load, lane l reading bytes 16 l .. 16 l + 15)
+//   T3   rows = particles, k = parameters   (distance operands)
+//   Vt3  rows = parameters, k = particles   (theta^T and score^T: the contraction's B operand; never staged in LDS)
+//   Each plane of a tile is stored in MFMA fragment order [row / 16][chunk][row % 16][8] (vfrag_offset), so the operand
+//   fragment of a 16-row block is ONE coalesced 1 KB load, lane l reading bytes 16 l .. 16 l + 15.  k_distance_x3 stages
+//   T3 through LDS chunk by chunk (its tile's rows may straddle two row blocks when a rank's row0 is not a multiple of
+//   128); k_distance_panel (stein_dpanel.hip) copies fragments into LDS and streams them into registers as they are.
 //
 // LDS image of a plane: [128 rows][64 B], chunk c of row r at 16 * (c ^ ((r >> 2) & 3)).  Conflict-free for
 //   ds_read_b128 fragments (16-lane groups {0-3,12-15,20-27}..., 64 banks): (4 row + chunk') mod 16 distinct in a group
@@ -55,13 +56,9 @@
 
 #include <stdlib.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
+#include "stein_x3_dev.h"
 constexpr int PEXP_H2 = 14;   // KIND 2: P = exp2(c D + 14), in (0, 2^14] (fp16 normal range down to P = 2^-28)
 template <int KIND> struct SplitTraits { static constexpr int pexp = KIND == 2 ? PEXP_H2 : 0; };
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // staging registers (native vector: stays in VGPRs)
 
 #ifdef STEIN_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of one wave per role and workgroup
 __device__ u64 g_stamps[8];
@@ -107,16 +104,7 @@ extern "C" int stein_debug_stamps(u64* host_out, int reset) {
 #define STAMP(k) do {} while (0)
 #endif
 
-constexpr int XROW = 64;                 // bytes per LDS row: 32 bf16
-constexpr int XPLANE = 128 * XROW;       // one 128-row plane of a tile: 8192 B
-constexpr int XTILE_E = 128 * 32;        // elements of one plane of a tile
 __device__ __forceinline__ int xswz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
-// Vt3 plane, element offset of 16-byte chunk `chunk` (8 consecutive k starting at 8 chunk) of row `row` (0..127):
-// fragment order [row / 16][chunk][row % 16][8], i.e. the B fragment of a 16x16x32 MFMA (16 rows x 32 k) is 1 KB
-// contiguous and lane l = 16 chunk + row % 16 reads bytes 16 l .. 16 l + 15
-__device__ __forceinline__ int vfrag_offset(int row, int chunk) {
-  return (((row >> 4) * 4 + chunk) * 16 + (row & 15)) * 8;
-}
 // LDS image of a P plane in the contraction: [128 rows][64 B], chunk c of row r at 16 * (c ^ g((r >> 2) & 3)) with
 // g = {0, 2, 3, 1}.  The 16x16x32 A fragment (lane l: row l & 15, chunk l >> 4) is read by ds_read_b128 in the lane
 // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: each holds the 16 rows once, with chunk c for rows 0-3 / 12-15
@@ -246,7 +234,7 @@ __global__ __launch_bounds__(256) void k_make_scales(const u32* __restrict__ cma
 }
 
 // One 64x64 tile of X [n][d] per workgroup.
-//   R  != NULL: tile-major image with rows = X rows (dk / 32 k tiles per row block), not swizzled, rows < r_rows, k < dk
+//   R  != NULL: tile-major image with rows = X rows (dk / 32 k tiles per row block), fragment order, rows < r_rows, k < dk
 //   Tt != NULL: tile-major image with rows = X columns (nk / 32 k tiles per row block), pre-swizzled, rows < dc, k < nk
 // The grid covers the padded extents; out-of-range source entries are written as zero.
 __device__ __forceinline__ float load_as_f32(const float* p) { return *p; }
@@ -287,7 +275,7 @@ __global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const
       u32 wa[3], wb[3];
       split_pair<KIND>(v[0] * sa, v[1] * sa, wa);
       split_pair<KIND>(v[2] * sa, v[3] * sa, wb);
-      u16* dst = R + (((size_t)(row >> 7) * ntk_r + (col >> 5)) * 3) * XTILE_E + (row & 127) * 32 + (col & 31);
+      u16* dst = R + (((size_t)(row >> 7) * ntk_r + (col >> 5)) * 3) * XTILE_E + vfrag_offset(row & 127, (col & 31) >> 3) + (col & 7);
 #pragma unroll
       for (int s = 0; s < KIND; ++s) *reinterpret_cast<uint2*>(dst + s * XTILE_E) = make_uint2(wa[s], wb[s]);
     }
@@ -329,7 +317,7 @@ __global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const
 //   blocks of T3, so each thread keeps its two source pointers; k tile / plane steps are uniform immediates.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ const u16* t3_chunk_ptr(const u16* __restrict__ T3, long ntk, long grow, int c16) {
-  return T3 + ((size_t)(grow >> 7) * ntk * 3) * XTILE_E + (grow & 127) * 32 + c16 * 8;
+  return T3 + ((size_t)(grow >> 7) * ntk * 3) * XTILE_E + vfrag_offset((int)(grow & 127), c16);
 }
 
 template <int NP>
@@ -352,11 +340,8 @@ __device__ __forceinline__ void x3_store_swz(unsigned char* oper, int t, const u
     }
 }
 
-// The products of one fragment pair, smallest first (plane 0 = most significant term).  NP is the split KIND = the
-// number of planes: 2 -> three fp16 products, 1 -> one bf16 product.  Fragments are held
-// as 32-bit vectors and bit-cast at the MFMA (loop-carried 16-bit vectors get scalarised by the compiler).
-#define X3_BF(v) __builtin_bit_cast(bf16x8, v)
-#define X3_HF(v) __builtin_bit_cast(f16x8, v)
+// The products of one fragment pair on the 32x32x16 shape, smallest first (plane 0 = most significant term; NP planes:
+// 2 -> three fp16 products, 1 -> one bf16 product).  X3_BF / X3_HF and the 16x16x32 form: stein_x3_dev.h
 template <int NP>
 __device__ __forceinline__ f32x16 x3_products(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
   if (NP == 2) {
@@ -367,16 +352,6 @@ __device__ __forceinline__ f32x16 x3_products(const u32x4 (&a)[3], const u32x4 (
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(X3_BF(a[0]), X3_BF(b[0]), c, 0, 0, 0);
 }
 
-// the same products on the 16x16x32 shape (one MFMA covers a whole 32-deep k tile)
-template <int NP>
-__device__ __forceinline__ f32x4 x3_products16(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
-  if (NP == 2) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[1]), X3_HF(b[0]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[0]), X3_HF(b[1]), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(X3_HF(a[0]), X3_HF(b[0]), c, 0, 0, 0);
-  }
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(X3_BF(a[0]), X3_BF(b[0]), c, 0, 0, 0);
-}
 
 // one 32-deep k tile already in LDS: 2 k16 steps x (2x2 tiles) x NP-dependent products
 template <int NP>
@@ -536,18 +511,7 @@ constexpr int FS_THREADS = 768;
 // "+v" operands made the compiler copy the (not yet landed) registers in front of the wait.  Loads complete in issue
 // order per wave.  After every change here: check in the .s that no v_mov / spill touches a destination register between
 // its load and its wait.
-typedef float f32x4g __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void stream_load16(f32x4g& dst, const void* base /* wave-uniform */, u32 byte_off) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base));
-}
-__device__ __forceinline__ void stream_load16(u32x4& dst, const void* base /* wave-uniform */, u32 byte_off) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base));
-}
-template <int N>
-__device__ __forceinline__ void stream_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
+// (stream_load16 / stream_wait: stein_x3_dev.h)
 // k tiles per pipeline stage (even: tile parity picks the register set) and the LDS of one k tile (NP planes, packed)
 // RB = 16-row blocks of the workgroup's tile: 8 -> 128 rows x 256 columns of [G | theta]; 4 -> 64 rows x 512 columns: the
 // P tile, whose exp / split work shares the SIMDs' issue slots with the MFMAs, is then built once per 512 columns, and
@@ -1099,8 +1063,11 @@ static void launch_distance_x3(long nblk, hipStream_t stream, const u16* T3, int
 
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                       int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,
-                      hipStream_t stream, SpecState* spec, u64* spec_buf) {
+                      hipStream_t stream, SpecState* spec, u64* spec_buf, int panel) {
   (void)d;
+  if (panel >= 0 && stein_dpanel_ok(L, dtype, n, row0, n_local, hist0 != nullptr && spec == nullptr, panel > 0))
+    return stein_dpanel_distance(planes, L, dtype, r_all, dist_out, n, row0, n_local, ld_dist, symmetric, stream, spec,
+                                 spec_buf);
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
   const float* two_s = reinterpret_cast<const float*>(planes + L.x3_sc) + 4 * L.x3_dc + 1;
   const int ntk = (int)(L.x3_dk / 32);

@@ -1082,7 +1082,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
-  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW | STEIN_FLAG_TILE_DISTANCE)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -1242,7 +1242,7 @@ static int distance_block_impl(const void* theta_all, const float* r_all, int64_
     int rc = stein_make_layout(n_local, n, d, dtype, STEIN_FLAG_X3, &L);
     if (rc) return rc;
     return stein_x3_distance((const char*)x3_planes, L, dtype, r_all, dist_out, n, d, row0, n_local, ld_dist, h0, sym, s,
-                             spec, spec_buf);
+                             spec, spec_buf, (flags & STEIN_STAGE_TILES) ? -1 : ((flags & STEIN_STAGE_PANEL) ? 1 : 0));
   }
   const bool vec = (d % 4 == 0) && (((uintptr_t)theta_all & 15) == 0);
   const float* T = (const float*)theta_all;
@@ -1633,7 +1633,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   void* planes = (flags & STEIN_FLAG_X3) ? ws + L.off[STEIN_WS_PLANES] : nullptr;
   // single rank: the block is the whole symmetric matrix -> upper-triangle distance pass with mirrored stores,
   // level-0 histogram taken in its epilogue, levels 1-2 read the upper triangle only
-  const int sf = STEIN_STAGE_SYMMETRIC;
+  const int sf = STEIN_STAGE_SYMMETRIC | ((flags & STEIN_FLAG_TILE_DISTANCE) ? STEIN_STAGE_TILES : 0);
   SpecState* spec = (SpecState*)((char*)sel + sizeof(SelState));
   u64* spec_buf = (u64*)(ws + L.off[STEIN_WS_SPEC]);
   hipStream_t s = (hipStream_t)stream;

@@ -88,17 +88,18 @@ class HipStages:
     def rownorms(self, T, n, d, r):
         _lib.call_on(T.device, "stein_rownorms", _ptr(T), n, d, _dt(T), _ptr(r), _stream(T))
 
-    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None):
+    def distance_block(self, T, r, n, d, row0, n_local, D, ld, hist0=None, symmetric=False, planes=None, kernel=0):
+        """kernel: 0 = the library's choice, _lib.STAGE_TILES / _lib.STAGE_PANEL = force one form of the split path's pass"""
         _lib.call_on(T.device, "stein_distance_block", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
-                  _ptr(planes), _lib.STAGE_SYMMETRIC if symmetric else 0, _stream(T))
+                  _ptr(planes), (_lib.STAGE_SYMMETRIC if symmetric else 0) | kernel, _stream(T))
 
     # -- speculative median window across ranks (include/steinhip.h) --
     def spec_begin(self, hist, sel, spec, total):
         _lib.call_on(hist.device, "stein_spec_begin", _ptr(hist), _ptr(sel), _ptr(spec), total, _stream(hist))
 
-    def distance_block_spec(self, T, r, n, d, row0, n_local, D, ld, hist0, sel, spec, planes=None):
+    def distance_block_spec(self, T, r, n, d, row0, n_local, D, ld, hist0, sel, spec, planes=None, kernel=0, symmetric=False):
         _lib.call_on(T.device, "stein_distance_block_spec", _ptr(T), _ptr(r), n, d, row0, n_local, _dt(T), _ptr(D), ld, _ptr(hist0),
-                  _ptr(planes), 0, _ptr(sel), _ptr(spec), _stream(T))
+                  _ptr(planes), (_lib.STAGE_SYMMETRIC if symmetric else 0) | kernel, _ptr(sel), _ptr(spec), _stream(T))
 
     def spec_tally(self, sel, spec):
         _lib.call_on(sel.device, "stein_spec_tally", _ptr(sel), _ptr(spec), _stream(sel))
@@ -196,7 +197,7 @@ class SvgdEngine:
     _full_distance_image = False   # set by scratch/ab.py for -DSTEIN_NO_UPPER builds (the mirrored image of round 1)
 
     def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True,
-                 window=True, force_collectives=False, comm="auto"):
+                 window=True, force_collectives=False, comm="auto", tile_distance=False):
         self.n, self.d = int(n), int(d)
         # dtype of the theta / score tensors handed to compute_phi: float32, or bfloat16 (BASELINE config 2: the
         # values are used as they are, K is rounded to bf16, one bf16 MFMA per product, fp32 accumulation)
@@ -212,8 +213,10 @@ class SvgdEngine:
         # small=False: the fused call never takes the one-kernel path for n <= 160 (tests of the tiled kernels)
         # window=False: the fused call never uses the speculative median window (every step pays the radix-select passes;
         # same results -- bench.py times the miss path this way)
+        # tile_distance=True: the fused call's distance pass always runs the per-tile kernel (A/B against the
+        # panel-resident kernel that large blocks with d <= 256 take by default, stein_dpanel.hip)
         self.flags = ((_lib.FLAG_X3 if self.x3 else 0) | (0 if small else _lib.FLAG_TILED) |
-                      (0 if window else _lib.FLAG_NO_WINDOW))
+                      (0 if window else _lib.FLAG_NO_WINDOW) | (_lib.FLAG_TILE_DISTANCE if tile_distance else 0))
         # several ranks: use the speculative median window (ONE 512 KB all-reduce and a hit-flag read-back per step
         # instead of three histogram all-reduces and two passes over the local distance block) when the block is large
         # enough for that to pay (>= 2^24 entries; every collective costs ~30 us of host time from Python, and the
@@ -515,7 +518,8 @@ class SvgdEngine:
         mark("contract")
         st.contract_partial(D, ld, T_all, G_all, n, d, self.row0, nl, self.h2, self.ws, planes, upper)
         mark("finish")
-        st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws, self.flags)
+        st.contract_finish(T_all, n, d, self.row0, nl, self.h2, self.phi, self.sqnorm, dK_out, self.ws,
+                           self.flags & ~_lib.FLAG_TILE_DISTANCE)
         if self.sharded:
             dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
         mark("end")

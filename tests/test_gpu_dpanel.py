@@ -1,0 +1,142 @@
+"""GPU: the panel-resident distance kernel (stein_amd/csrc/stein_dpanel.hip) against the per-tile kernel and the fp64
+formula D = r + r^T - 2 T T^T (stein/kernels/abstract_kernel.py:33-35), on shapes small enough to force it everywhere:
+ragged k extents (d = 100, 200), bf16 inputs, a symmetric matrix (upper tiles only, diagonal tiles mirrored by value) and
+a row block off the origin; the speculative median window fed by its epilogue (counting proof of the two order statistics
+on the kernel's own image); and the fused call at the smallest size that takes it by itself."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from stein_amd import _lib
+from stein_amd.engine import SvgdEngine, untile_distances
+from test_gpu_baseline_sizes import check_exact_bandwidth
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, d, device, dtype=torch.float32, seed=0):
+    T = torch.tensor(np.random.default_rng(seed).normal(size=(n, d)), dtype=torch.float32)
+    G = torch.tensor(np.random.default_rng(seed + 1).normal(size=(n, d)), dtype=torch.float32)
+    if dtype == torch.bfloat16:
+        T, G = T.bfloat16().float(), G.bfloat16().float()
+    return T.to(device), G.to(device)
+
+
+def _fp64_dist(T, rows=None):
+    Ta = T.double()
+    ra = (Ta * Ta).sum(1)
+    Ti = Ta if rows is None else Ta[rows]
+    ri = ra if rows is None else ra[rows]
+    return ri[:, None] + ra[None, :] - 2.0 * (Ti @ Ta.T)
+
+
+@pytest.mark.parametrize("n,d,dtype", [(1024, 256, torch.float32), (768, 200, torch.float32), (512, 100, torch.float32),
+                                       (640, 33, torch.float32), (1024, 128, torch.bfloat16), (512, 300, torch.bfloat16)])
+def test_panel_symmetric_matches_tile_kernel_and_fp64(cuda, n, d, dtype):
+    T, G = _inputs(n, d, cuda, dtype)
+    eng = SvgdEngine(n, d, device=cuda, x3=True, dtype=dtype, small=False)
+    st = eng.stages
+    Td = T.to(dtype)
+    st.rownorms(Td, n, d, eng.rownorm)
+    st.x3_prepare(Td, G.to(dtype), n, d, eng.planes)
+    out = {}
+    for name, kernel in (("tiles", _lib.STAGE_TILES), ("panel", _lib.STAGE_PANEL)):
+        eng.dist.fill_(float("nan"))
+        st.distance_block(Td, eng.rownorm, n, d, 0, n, eng.dist, eng.ld_dist, symmetric=True, planes=eng.planes, kernel=kernel)
+        torch.cuda.synchronize()
+        # the stored image: every tile on and above the diagonal is complete, nothing else was touched
+        v = eng.dist.view(n // 128, eng.ld_dist // 32, 128, 32)
+        for I in range(n // 128):
+            assert bool(torch.isfinite(v[I, 4 * I:n // 32]).all()), (name, "missing entries in row tile", I)
+            assert bool(torch.isnan(v[I, :4 * I]).all()), (name, "wrote below the diagonal", I)
+            dg = v[I, 4 * I:4 * I + 4].permute(1, 0, 2).reshape(128, 128)
+            assert torch.equal(dg, dg.T), (name, "diagonal tile not symmetric", I)
+        out[name] = untile_distances(eng.dist, n, n, upper=True)
+    ref = _fp64_dist(T)
+    scale = ref.abs().max().item()
+    tol = 4e-6 if dtype == torch.float32 else 2e-5
+    for name, M in out.items():
+        assert torch.equal(M, M.T)
+        assert (M.double() - ref).abs().max().item() <= tol * scale, name
+    # the two kernels sum the same products in a different order: equal to rounding of the accumulation
+    assert (out["panel"] - out["tiles"]).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("n,d,row0,nl", [(1024, 256, 256, 512), (1536, 96, 1280, 256), (512, 256, 0, 512)])
+def test_panel_row_block_matches_fp64(cuda, n, d, row0, nl):
+    """non-symmetric row block [row0, row0 + nl) of the n columns, every tile stored"""
+    T, G = _inputs(n, d, cuda, seed=3)
+    st = SvgdEngine(8, 2, device=cuda).stages
+    total, offs, extra = st.workspace_layout(nl, n, d, _lib.FLAG_X3)
+    ws = torch.zeros(total, dtype=torch.uint8, device=cuda)
+    ld = extra[_lib.WSX_LD_DIST]
+    r = ws[offs[_lib.WS_ROWNORM]:offs[_lib.WS_ROWNORM] + 4 * n].view(torch.float32)
+    D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nl * ld * 4].view(torch.float32).view(nl, ld)
+    planes = ws[offs[_lib.WS_PLANES]:total]
+    st.rownorms(T, n, d, r)
+    st.x3_prepare(T, G, n, d, planes)
+    ref = _fp64_dist(T, torch.arange(row0, row0 + nl, device=cuda))
+    mats = {}
+    for name, kernel in (("tiles", _lib.STAGE_TILES), ("panel", _lib.STAGE_PANEL)):
+        D.fill_(float("nan"))
+        st.distance_block(T, r, n, d, row0, nl, D, ld, planes=planes, kernel=kernel)
+        torch.cuda.synchronize()
+        mats[name] = untile_distances(D, nl, n)
+        assert (mats[name].double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item(), name
+    assert (mats["panel"] - mats["tiles"]).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_panel_feeds_the_median_window(cuda, sym):
+    """Window form of the staged calls on one rank: the panel kernel's epilogue counts the entries below the window and
+    collects those inside it; tally + pick then deliver the exact order statistics of the kernel's own image."""
+    n, d = 1024, 64
+    T, G = _inputs(n, d, cuda, seed=5)
+    eng = SvgdEngine(n, d, device=cuda, x3=True, small=False)
+    for _ in range(4):      # fused steps give the predictor its history (the particles drift a little per step)
+        eng.compute_phi(T, G)
+        T = T + 1e-3 * eng.phi
+    st, hist, sel, spec = eng.stages, eng.hist, eng.select_state, eng.spec_section
+    state = sel.clone()
+    h2, med = torch.zeros(1, device=cuda), torch.zeros(1, device=cuda)
+    st.rownorms(T, n, d, eng.rownorm)
+    st.x3_prepare(T, G, n, d, eng.planes)
+    got = {}
+    for name, kernel in (("tiles", _lib.STAGE_TILES), ("panel", _lib.STAGE_PANEL)):
+        sel.copy_(state)
+        st.spec_begin(hist, sel, spec, n * n)
+        st.distance_block_spec(T, eng.rownorm, n, d, 0, n, eng.dist, eng.ld_dist, hist[0], sel, spec, planes=eng.planes,
+                               kernel=kernel, symmetric=sym)
+        st.spec_tally(sel, spec)
+        st.spec_pick(sel, spec, n, h2, med)
+        torch.cuda.synchronize()
+        flags = sel[_lib.SPEC_HIT_OFFSET:_lib.SPEC_SKIP_L0_OFFSET + 4].view(torch.int32).cpu()
+        assert int(flags[0]) == 1, (name, "the window missed")
+        got[name] = check_exact_bandwidth([eng.dist], sel.view(torch.float32), n, h2.item(), upper=sym)
+    assert abs(got["panel"] - got["tiles"]) <= 4e-7 * got["tiles"]
+
+
+def test_fused_call_takes_the_panel_kernel_and_stays_exact(cuda):
+    """n = 8192, d = 40: the smallest block the fused call gives to the panel kernel by itself.  Every step's bandwidth
+    is the exact median of that step's own distances (first steps: radix select with the level-0 pass the panel kernel
+    asks for; later: the window), equal to the per-tile kernel's to rounding, and so is phi."""
+    n, d = 8192, 40
+    T, G = _inputs(n, d, cuda, seed=7)
+    eng = SvgdEngine(n, d, device=cuda, x3=True)
+    ref = SvgdEngine(n, d, device=cuda, x3=True, tile_distance=True)
+    hits = 0
+    for step in range(5):
+        phi = eng.compute_phi(T, G).clone()
+        phi_ref = ref.compute_phi(T, G)
+        torch.cuda.synchronize()
+        h2 = check_exact_bandwidth([eng.dist], eng.select_state.view(torch.float32), n, eng.h2.item(), upper=True)
+        assert abs(h2 - ref.h2.item()) <= 4e-7 * h2
+        assert ((phi - phi_ref).norm() / phi_ref.norm()).item() <= 2e-6
+        M = eng.dist_matrix()
+        assert torch.equal(M, M.T)
+        hits = eng.window_stats()[1]
+        T = T + 1e-3 * phi
+    assert hits >= 2
+    assert not math.isnan(eng.h2.item())

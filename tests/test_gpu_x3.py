@@ -48,7 +48,7 @@ def test_split_planes_reconstruct_fp32(cuda):
         x = flat.view(nrows // 128, nks // 32, 3, 128, 32)[:, :, :kind].double().sum(2)
         return x.permute(0, 2, 1, 3).reshape(nrows, nks)
 
-    t3 = untile(raw[:3 * rows * dk], rows, dk, False)
+    t3 = untile(raw[:3 * rows * dk], rows, dk, True)
     off = (3 * rows * dk * 2 + 255) // 256 * 256 // 2
     tt3 = untile(raw[off:off + 3 * dc * nk], dc, nk, True)
     off2 = off + (3 * dc * nk * 2 + 255) // 256 * 256 // 2
