@@ -13,7 +13,7 @@ def main():
     objs, procs = [], []
     for src in ge.SRCS:
         base = os.path.basename(src)
-        if base in ("stein_x3.hip", "steinhip.hip"):
+        if base in ("stein_x3.hip", "steinhip.hip", "stein_dpanel.hip"):
             obj = os.path.join(tmp, base + ".o")
             procs.append(subprocess.Popen([ge._hipcc()] + ge.HIPCC_FLAGS + flags + ["-c", src, "-o", obj]))
         else:

@@ -28,6 +28,7 @@
 // (i, j) for i <= j and, for i < j, the same VALUE at (j, i) -- D is exactly symmetric whatever the product order was.
 #include "stein_x3.h"
 #include "stein_x3_dev.h"
+#include "stein_ablate.h"
 
 constexpr int DP_THREADS = 512;        // 8 waves: two per SIMD
 constexpr int DP_RING = 4;             // k tiles of the strip operand in flight per wave
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   constexpr int LPS = 2 * NP;                  // streamed loads per k tile: 2 column blocks x NP planes
   constexpr int W_LATE = 3 * LPS;              // the loads of the three k tiles behind the one waited for stay in flight
   constexpr int W_EARLY = 3 * LPS + 16 + 2;    // ... and the 16 D stores and 2 norm loads issued between its request and its use
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS + 16];
+  u32* const dealer = reinterpret_cast<u32*>(smem + DP_LDS);   // the next strip of the segment nobody has taken yet
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   unsigned char* const panel = smem;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   u32x4 ring[DP_RING][2][3];
   f32x4g rj[2];
   float ri[8];
+  DP_STAMP_DECL;
 
   for (; I < tiles_m && dp_prefix<SYM>(I, tiles_n) < c1; ++I) {
     const long base = dp_prefix<SYM>(I, tiles_n) + DP_SWITCH;
@@ -205,10 +208,14 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
       // knows about) would sit in every strip's epilogue and drain the streamed loads in flight there
 #pragma unroll
       for (int ib = 0; ib < 8; ++ib) asm volatile("" : "+v"(ri[ib]));
+      if (t == 0) *dealer = (u32)(sb + 8);
     }
     __syncthreads();
+    DP_STAMP(4);
 
-    // ---- the wave's strips: sb + w, sb + w + 8, ... ---------------------------------------------------------------------
+    // ---- the wave's strips: sb + w first, then whichever strip of the segment is next (an LDS counter deals them: at
+    // equal priority the older wave of a SIMD wins every issue arbitration and a static deal left the younger one to finish
+    // a quarter of its strips alone, with nothing to overlap its epilogues with) -------------------------------------------
     int s = sb + w;
     if (s < se) {
       auto strip_base = [&](int strip) {           // operand fragments of column strip `strip` (k tile 0, plane 0, block 0)
@@ -232,8 +239,12 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
 #pragma unroll
       for (int u = 0; u < DP_RING; ++u) request(cur, u, ring[u]);
       bool regular = false;                        // the previous epilogue issued exactly 16 stores + 2 norm loads
-      for (; s < se; s += 8) {
-        const int snext = s + 8 < se ? s + 8 : s;
+      for (;;) {
+        u32 drawn = 0u;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(dealer, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int sdrawn = __builtin_amdgcn_readfirstlane((int)drawn);
+        const bool more = sdrawn < se;
+        const int snext = more ? sdrawn : s;       // (no next strip: the trailing requests re-read this one)
         const u16* nxt = strip_base(snext);
         f32x4 acc[8][2];
 #pragma unroll
@@ -245,13 +256,17 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
 #pragma unroll
           for (int u = 0; u < DP_RING; ++u) {
             const int kt = g * DP_RING + u;
+            DP_STAMP(2);
             if (g == 0 && regular) stream_wait<W_EARLY>(); else stream_wait<W_LATE>();
+            DP_STAMP(0);
             if (kt < ntk) dp_step<NP>(panel + kt * NP * XPLANE + aoff, ring[u], acc);
+            DP_STAMP(1);
             request(last ? nxt : cur, last ? u : kt + DP_RING, ring[u]);
           }
         }
         // the strip's column norms were requested a whole k loop ago; with more than one group of k tiles the loop's own
         // waits have covered them, with a single group only the 4 requests of this loop are younger
+        DP_STAMP(2);
         if (groups == 1) stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
         const int c32 = cfirst + s;
@@ -299,10 +314,17 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
         request_norms(snext);                      // ("memory": the strip's stores are issued before this point)
         cur = nxt;
+        DP_STAMP(3);
+        DP_STAMP_COUNT(5);
+        if (!more) break;
+        s = snext;
       }
       stream_wait<0>();                            // the trailing re-reads land before their registers move on
     }
+    DP_STAMP(4);
   }
+  DP_STAMP_FLUSH(lane);
+  DP_STAMP_WG(p, w, lane);
   if (window) {
     dp_flush(sx, spec, spec_buf, lane);
     if (lane == 0) {

@@ -188,10 +188,11 @@ class SvgdEngine:
     group   : torch.distributed process group (None -> single rank).  n must divide evenly.
     stages  : backend implementing the staged calls; the product default is HipStages.
               (tests substitute a NumPy model to exercise the collective protocol on CPU/gloo.)
-    comm    : who issues the collectives of a sharded step.  "native": the library, on its own RCCL communicator, the
-              whole step one C call (stein_rank_step).  "torch": torch.distributed collectives between the rank
-              segments.  "auto" (default): native on GPUs with the HIP stages when the group's backend is nccl (RCCL),
-              torch otherwise.
+    comm    : who issues the collectives of a sharded step.  "torch" (and "auto", the default): torch.distributed
+              collectives between the rank segments -- the path every multi-rank test has run.  "native": the library,
+              on its own RCCL communicator, the whole step one C call (stein_rank_step; 68 us of host time per step
+              against ~190).  Native is opt-in until a run on two or more GPUs has passed bench.py's native-vs-torch
+              cross-check: so far it has only ever seen one-rank groups, where every collective is a self-copy.
     """
 
     _full_distance_image = False   # set by scratch/ab.py for -DSTEIN_NO_UPPER builds (the mirrored image of round 1)
@@ -265,28 +266,60 @@ class SvgdEngine:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
         self.dist_upper = False      # the distance image holds only the tiles on and above the diagonal (set per step)
+        # the fused call takes the one-kernel path for this shape (stein_small.hip: n <= 160): no distance image exists.
+        # The layout tells: only then is the SPEC section of the workspace empty (stein_make_layout)
+        self._one_kernel = (not self.sharded) and offs[_lib.WS_PLANES] == offs[_lib.WS_SPEC]
+        self._have_dist = False
         self._flags_host = None      # page-locked landing place of the window's hit flag (HIP stages, window form)
         self._flags_event = None
         if comm not in ("auto", "native", "torch"):
             raise ValueError("comm must be 'auto', 'native' or 'torch'")
         self._comm = None
-        if self.sharded and comm != "torch":
+        self.comm_error = None       # why comm="native" could not be set up (the same text on every rank)
+        if self.sharded and comm == "native":
             import torch.distributed as dist
             able = self.device.type == "cuda" and hasattr(self.stages, "rank_step") and "nccl" in str(dist.get_backend(group))
-            if comm == "native" and not able:
+            if not able:             # a property of the group and the stages: every rank decides the same
                 raise ValueError("comm='native' needs CUDA/HIP tensors, the HIP stages and an nccl (RCCL) process group")
-            if able:
-                self._comm = self._make_native_comm()
+            self._comm = self._make_native_comm()
+            if self._comm is None:   # decided collectively: every rank raises
+                raise RuntimeError("comm='native': " + self.comm_error)
         self.comm = "native" if self._comm is not None else ("torch" if self.sharded else None)
 
     def _make_native_comm(self):
-        """group rank 0 makes the 128-byte RCCL id, the group broadcasts it, every rank joins (collective)."""
+        """Group rank 0 makes the 128-byte RCCL id, the group broadcasts it, every rank joins -- collective, and
+        collective in failure too: every rank takes part in the same two torch collectives whatever happens to it, so
+        that a rank whose RCCL is missing (or whose ncclCommInitRank fails) cannot leave the others waiting inside a
+        broadcast.  Returns the communicator, or None on EVERY rank (self.comm_error says why)."""
         import torch.distributed as dist
-        uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+        src = dist.get_global_rank(self.group, 0)
+        msg = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8, device=self.device)   # id | status byte (1 = id valid)
         if self.rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(self.stages.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, src=dist.get_global_rank(self.group, 0), group=self.group)
-        return self.stages.comm_init(self.device, bytes(uid.cpu().numpy().tobytes()), self.world, self.rank)
+            try:
+                uid0 = self.stages.comm_unique_id()
+                msg[:_lib.COMM_ID_BYTES].copy_(torch.frombuffer(bytearray(uid0), dtype=torch.uint8))
+                msg[_lib.COMM_ID_BYTES] = 1
+            except Exception as e:      # rank 0 still broadcasts: the status byte tells the others
+                self.comm_error = "rank 0 could not make an RCCL id: %s" % e
+        dist.broadcast(msg, src=src, group=self.group)
+        host = msg.cpu()
+        comm, err = None, None
+        if int(host[_lib.COMM_ID_BYTES]) == 1:
+            try:
+                comm = self.stages.comm_init(self.device, bytes(host[:_lib.COMM_ID_BYTES].numpy().tobytes()), self.world,
+                                             self.rank)
+            except Exception as e:
+                err = "rank %d could not join the communicator: %s" % (self.rank, e)
+        else:
+            err = self.comm_error or "rank 0 could not make an RCCL id"
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 1:
+            return comm
+        if comm is not None:            # some other rank failed: nobody keeps a communicator
+            self.stages.comm_destroy(comm)
+        self.comm_error = err or "another rank could not join the communicator"
+        return None
 
     def close(self):
         """release the library's communicator (collective-free; safe to call twice)"""
@@ -319,6 +352,9 @@ class SvgdEngine:
     def dist_matrix(self):
         """Row-major [n_local, n] copy of the distance block (de-tiled; for inspection and tests).  After a single-rank
         step on the split path only the tiles on and above the diagonal are stored; the rest is mirrored in here."""
+        if not self._have_dist:
+            raise RuntimeError("no distance image: nothing has run yet, or the last step took the one-kernel path "
+                               "(n <= 160), which keeps D in LDS; build the engine with small=False to get one")
         return untile_distances(self.dist, self.n_local, self.n, upper=self.dist_upper)
 
     @property
@@ -462,15 +498,18 @@ class SvgdEngine:
         if not self.sharded and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
                         self.flags | (_lib.FLAG_TIMING if timing else 0))
-            self.dist_upper = self.x3
+            self._have_dist = not self._one_kernel
+            self.dist_upper = self.x3 and self._have_dist and not SvgdEngine._full_distance_image
             return self.phi
         if self.sharded and mark is None and K_out is None and self._comm is not None:
             flags = ((self.flags & _lib.FLAG_X3) | (_lib.FLAG_RANK_WINDOW if self.dist_window else 0) |
                      (_lib.FLAG_TIMING if timing else 0))
             self.window_hit = st.rank_step(self._comm, theta_local, score_local, self.T_all, self.G_all, n, d, self.phi,
                                            self.h2, self.median, self.sqnorm, dK_out, self.ws, flags)
+            self._have_dist, self.dist_upper = True, False
             return self.phi
         if self.sharded and mark is None and K_out is None and hasattr(st, "rank_begin"):
+            self._have_dist, self.dist_upper = True, False
             return self._sharded_step(theta_local, score_local, dK_out, timing)
         if mark is None:
             def mark(label):
@@ -508,7 +547,7 @@ class SvgdEngine:
         upper = sym and planes is not None     # what the symmetric distance pass of the split path stores
         if SvgdEngine._full_distance_image:     # A/B scripts against -DSTEIN_NO_UPPER builds of the library only
             upper = False
-        self.dist_upper = upper
+        self.dist_upper, self._have_dist = upper, True
         if K_out is not None:
             st.kernel_matrix(D, ld, nl, n, self.h2, K_out, upper)
         if gather_g is not None:

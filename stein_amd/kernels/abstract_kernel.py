@@ -49,7 +49,7 @@ class AbstractKernel:
         st = eng.stages
         st.rownorms(T, eng.n, eng.d, eng.rownorm)
         st.distance_block(T, eng.rownorm, eng.n, eng.d, 0, eng.n, eng.dist, eng.ld_dist)
-        eng.dist_upper = False      # a full (fp32-MFMA, non-symmetric) image
+        eng.dist_upper, eng._have_dist = False, True      # a full (fp32-MFMA, non-symmetric) image
         D = eng.dist_matrix()
         return D.cpu().numpy() if was_numpy else D
 

@@ -136,12 +136,38 @@ class AbstractSteinSampler:
         return g.to(device=self.device, dtype=self.kernel_dtype).contiguous()
 
     # -- the hot path ---------------------------------------------------------------------------------
+    def _foreign_kernel(self):
+        """The reference's kernel seam (abstract_stein_sampler.py:103): any object with ``kernel_and_grad(theta) ->
+        (K, dK)`` drops in as ``sampler.kernel``.  Returns it when it is NOT this package's fused RBF kernel (whose K the
+        sampler never materialises), else None."""
+        k = getattr(self, "kernel", None)
+        if k is None:
+            return None
+        from ..kernels import SquaredExponentialKernel
+        return None if isinstance(k, SquaredExponentialKernel) else k
+
     def compute_phi(self, theta_array, grads_array):
         """phi = (K . grads + dK) / n for the given particles (abstract_stein_sampler.py:100-105).
 
         NumPy in -> float64 NumPy out (values carry fp32 precision); device tensors in -> float32 tensor out.
+        With a user-supplied ``self.kernel`` the reference's own lines run instead: ``K, dK =
+        self.kernel.kernel_and_grad(theta_array)``; ``(K.dot(grads_array) + dK) / n_particles`` in NumPy.
         """
         was_numpy = not isinstance(theta_array, torch.Tensor)
+        foreign = self._foreign_kernel()
+        if foreign is not None:
+            if self._group is not None:
+                raise ValueError("a user-supplied kernel needs all particles on one rank")
+            th = theta_array if was_numpy else theta_array.detach().double().cpu().numpy()
+            g = grads_array
+            if isinstance(g, dict):
+                g, _ = convert_dictionary_to_array(g)
+            g = g.detach().double().cpu().numpy() if isinstance(g, torch.Tensor) else np.asarray(g)
+            n_particles, n_params = g.shape                                  # abstract_stein_sampler.py:100
+            K, dK = foreign.kernel_and_grad(th)                              # :103
+            K, dK = (x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x) for x in (K, dK))
+            phi = (K.dot(g) + dK) / n_particles                              # :105
+            return phi if was_numpy else torch.as_tensor(phi).to(device=self.device, dtype=torch.float32)
         T = theta_array if not was_numpy else torch.from_numpy(np.ascontiguousarray(np.asarray(theta_array, dtype=np.float64)))
         T = T.to(device=self.device, dtype=self.kernel_dtype).contiguous()
         G = self._score_to_device(grads_array)
@@ -151,9 +177,29 @@ class AbstractSteinSampler:
     def update_particles(self, grads_array):
         """One SVGD step from the score matrix: phi, norm clip, optimizer apply
         (abstract_stein_sampler.py:121-127), all on device."""
+        if self._foreign_kernel() is not None or not hasattr(self.gd, "apply_"):
+            return self._update_particles_by_the_seams(grads_array)
         G = self._score_to_device(grads_array)
         phi = self.engine.compute_phi(self._theta_f32(), G)
         self.gd.apply_(self.theta_matrix, phi, self.engine.sqnorm)
+
+    def _update_particles_by_the_seams(self, grads_array):
+        """The reference's duck-typed seams, line for line (abstract_stein_sampler.py:121-127): taken when ``self.gd`` is a
+        reference-style optimizer (only ``update(phi) -> step``, no fused ``apply_``) or ``self.kernel`` is a user's
+        object (only ``kernel_and_grad``).  phi still comes from the HIP engine unless the kernel is foreign; the clip and
+        the optimizer run on the host in float64 as the reference's NumPy does."""
+        g = grads_array
+        if isinstance(g, dict):
+            g, _ = convert_dictionary_to_array(g)
+        g = g.detach().double().cpu().numpy() if isinstance(g, torch.Tensor) else np.asarray(g, dtype=np.float64)
+        theta_array = self.theta_matrix.detach().double().cpu().numpy()      # :121 (a float64 copy, as the reference packs)
+        phi = self.compute_phi(theta_array, g)                               # :123
+        # :125 -- on one rank NumPy's norm of phi, as the reference; sharded, phi holds this rank's rows and the norm is the
+        # engine's all-reduced one
+        norm = np.linalg.norm(phi) if self._group is None else float(self.engine.sqnorm.sqrt().item())
+        phi *= 10. / max(10., norm)
+        theta_array += self.gd.update(phi)                                   # :126
+        self.theta_matrix.copy_(torch.as_tensor(theta_array).to(self.theta_matrix))   # :127
 
     def function_posterior(self, func, feed_dict=None, axis=None):
         """Evaluate `func` under every particle (abstract_stein_sampler.py:157-168).

@@ -23,7 +23,9 @@ class SteinSampler(AbstractSteinSampler):
         super().__init__(n_particles, log_p, theta, **kwargs)
         self.gd = gd
         self.score = score
-        # kept for API parity (stein_sampler.py:48); the sampler itself goes through self.engine
+        # stein_sampler.py:48.  While this is the package's own RBF kernel the sampler goes through the fused engine (K is
+        # never materialised); assign any other object with kernel_and_grad(theta) -> (K, dK) and update_particles /
+        # compute_phi call it exactly as the reference does (abstract_stein_sampler.py:103)
         from ..kernels import SquaredExponentialKernel
         self.kernel = SquaredExponentialKernel(self.n_particles, None, device=self.device) \
             if self._group is None else None

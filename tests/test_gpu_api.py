@@ -211,3 +211,104 @@ def test_sampler_state_roundtrip(cuda):
     b.update_particles(G)
     assert torch.equal(a.theta_matrix, b.theta_matrix)
     assert b.gd.n_iters == 2 and b.gd.learning_rate == pytest.approx(0.05 * 0.99 ** 2)
+
+
+# ---- the reference's duck-typed seams (abstract_stein_sampler.py:103, :126) ---------------------------------------------
+class _UpdateOnlyOptimizer:
+    """What the reference's sampler needs of `gd`: update(phi) -> step, nothing else.  Wraps the oracle's restatement
+    of adagrad_gradient_descent.py:37-44 / adam_gradient_descent.py:45-58 (pinned bit for bit by G1)."""
+
+    def __init__(self, state):
+        self._s = state
+
+    def update(self, phi):
+        return self._s.update(phi)
+
+
+class _RestatedKernel:
+    """What the reference's sampler needs of `kernel`: kernel_and_grad(theta) -> (K, dK); the stand-in the golden
+    generator used (tests/golden/make_golden.py: RestatedKernel)."""
+    calls = 0
+
+    def kernel_and_grad(self, theta):
+        from oracle import svgd_oracle as orc
+        _RestatedKernel.calls += 1
+        return orc.kernel_and_grad(theta, np.float32)
+
+
+@pytest.mark.parametrize("tag", ["noclip", "clip"])
+@pytest.mark.parametrize("oname", ["adagrad", "adam"])
+@pytest.mark.parametrize("standin", ["both", "gd", "kernel"])
+def test_g3_through_the_reference_seams(cuda, golden, tag, oname, standin):
+    """SteinSampler driven with the golden generator's stand-ins: an optimizer object exposing only .update and / or a
+    kernel object exposing only .kernel_and_grad.  With both, the reference's own NumPy lines run on the reference's own
+    stand-ins: G3 bit for bit.  With one, the HIP engine supplies phi (or the HIP optimizer the step): 1e-5."""
+    from oracle import svgd_oracle as orc
+    from stein_amd.samplers import SteinSampler
+    from stein_amd.optimizers import AdagradGradientDescent, AdamGradientDescent
+    g = golden("g3_update_particles.npz")
+    key = f"{tag}_{oname}"
+    if standin in ("both", "gd"):
+        gd = _UpdateOnlyOptimizer(orc.AdagradState(learning_rate=0.05) if oname == "adagrad"
+                                  else orc.AdamState(learning_rate=0.05, decay=0.99))
+        assert not hasattr(gd, "apply_")
+    else:
+        gd = AdagradGradientDescent(0.05) if oname == "adagrad" else AdamGradientDescent(0.05, decay=0.99)
+    v = Var("model/w:0", [10])
+    s = SteinSampler(100, None, gd, theta={v: g[key + "_T0"].copy()}, dtype=torch.float64)
+    calls0 = _RestatedKernel.calls
+    if standin in ("both", "kernel"):
+        s.kernel = _RestatedKernel()
+    for t, G in enumerate(g[key + "_G"]):
+        s.update_particles(G)
+        ref = g[key + "_theta"][t]
+        got = s.samples
+        if standin == "both":
+            assert np.array_equal(got, ref), (t, np.abs(got - ref).max())
+        else:
+            assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (t, np.abs(got - ref).max())
+        assert torch.equal(s.theta[v], s.theta_matrix.reshape(100, 10))
+    assert _RestatedKernel.calls - calls0 == (3 if standin in ("both", "kernel") else 0)
+    # compute_phi goes through the same seam (abstract_stein_sampler.py:103-105)
+    if standin in ("both", "kernel"):
+        T, G = g[key + "_T0"], g[key + "_G"][0]
+        K, dK = orc.kernel_and_grad(T, np.float32)
+        assert np.array_equal(s.compute_phi(T, G), (K.dot(G) + dK) / 100)
+
+
+def test_function_posterior_values_and_axis(cuda):
+    """function_posterior against the reference's per-particle loop (abstract_stein_sampler.py:157-168: np.ravel of
+    func under particle i, stacked to [n, out]; dist.mean(axis=axis) when axis is given), on the logistic example's
+    readout: `logits = X w` (examples/logistic_regression/main.py:39) as evaluate() uses it (:52-61)."""
+    from stein_amd.samplers import SteinSampler
+    from stein_amd.optimizers import AdamGradientDescent
+    rng = np.random.default_rng(12)
+    n, n_feats, n_test = 37, 6, 11
+    W = rng.normal(size=(n, n_feats, 1))
+    log_alpha = rng.normal(size=(n,))
+    X = rng.normal(size=(n_test, n_feats))
+    y = (rng.uniform(size=(n_test, 1)) > 0.5).astype(np.float64)
+    vw, va = Var("model/Variable:0", [n_feats, 1]), Var("model/Variable_1:0", [])
+    s = SteinSampler(n, None, AdamGradientDescent(), theta={vw: W.copy(), va: log_alpha.copy()}, dtype=torch.float64)
+    Xd = torch.tensor(X, dtype=torch.float64, device=cuda)
+
+    def logits(theta, feed):                       # batched over particles: [n, n_test, 1]
+        return feed["X"] @ theta[vw]
+
+    # the reference's loop, restated: one evaluation per particle, raveled, stacked
+    dist = np.array([np.ravel(X @ W[i]) for i in range(n)])
+    got = s.function_posterior(logits, {"X": Xd})
+    assert got.shape == (n, n_test) and got.dtype == np.float64
+    np.testing.assert_allclose(got, dist, rtol=1e-12, atol=1e-12)
+    for axis in (0, 1):
+        np.testing.assert_allclose(s.function_posterior(logits, {"X": Xd}, axis=axis), dist.mean(axis=axis), rtol=1e-12, atol=1e-12)
+    # evaluate() of the example: average the logits over the particles, threshold, compare with the labels
+    acc = np.mean((s.function_posterior(logits, {"X": Xd}).mean(axis=0) > 0.) == y.ravel())
+    assert acc == np.mean((dist.mean(axis=0) > 0.) == y.ravel())
+    # a func with a matrix-valued output per particle is raveled per particle (np.ravel), a scalar one gives [n, 1]
+    both = s.function_posterior(lambda th, feed: torch.stack([feed["X"] @ th[vw], -(feed["X"] @ th[vw])], dim=1), {"X": Xd})
+    np.testing.assert_allclose(both, np.array([np.ravel(np.stack([X @ W[i], -(X @ W[i])])) for i in range(n)]), rtol=1e-12)
+    sc = s.function_posterior(lambda th, feed: th[va].exp(), None)
+    assert sc.shape == (n, 1)
+    np.testing.assert_allclose(sc[:, 0], np.exp(log_alpha), rtol=1e-12)
+    assert s.function_posterior(lambda th, feed: th[va].exp(), None, axis=0).shape == (1,)
