@@ -15,12 +15,15 @@ def main():
         base = os.path.basename(src)
         if base in ("stein_x3.hip", "steinhip.hip", "stein_dpanel.hip"):
             obj = os.path.join(tmp, base + ".o")
-            procs.append(subprocess.Popen([ge._hipcc()] + ge.HIPCC_FLAGS + flags + ["-c", src, "-o", obj]))
+            audited = base in ge.ISA_CHECKED
+            procs.append((src, subprocess.Popen([ge._hipcc()] + ge.HIPCC_FLAGS + flags + (["-save-temps=obj"] if audited else []) +
+                                                ["-c", src, "-o", obj], stderr=subprocess.DEVNULL if audited else None)))
         else:
             obj = os.path.join(ge.OBJDIR, base + ".o")
         objs.append(obj)
-    for p in procs:
+    for src, p in procs:
         if p.wait(): raise SystemExit("compile failed")
+        ge._isa_check(src, tmp)     # the same assembly audit as the shipped build (a variant's register pressure differs)
     out = os.path.join(ROOT, "scratch", "lib_%s.so" % name)
     subprocess.run([ge._hipcc()] + ge.LINK_FLAGS + objs + ["-o", out], check=True)
     print(out)

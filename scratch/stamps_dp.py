@@ -9,7 +9,7 @@ lib = _lib.load()
 lib.stein_debug_dp.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 lib.stein_debug_dp_wg.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
 n, d = int(sys.argv[1]), int(sys.argv[2]); world = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # 0: the whole matrix through the staged call (SYM=1: symmetric)
-buf = (ctypes.c_uint64 * 10)()
+buf = (ctypes.c_uint64 * 12)()
 dev = "cuda"
 def report(tag, ms):
     a = np.array(list(buf), dtype=np.float64)
@@ -17,14 +17,27 @@ def report(tag, ms):
     tot = a[:5].sum()
     print("%s: %.3f ms  strips %d waves %d | cycles per strip and wave: wait %6.0f  reads+MFMA %6.0f  requests %5.0f  epilogue %6.0f  switches %5.0f  total %6.0f | per wave %.0f cycles"
           % (tag, ms, strips, waves, a[0] / strips, a[1] / strips, a[2] / strips, a[3] / strips, a[4] / strips, tot / strips, tot / waves), flush=True)
-    wg = (ctypes.c_uint64 * 768)()
+    wg = (ctypes.c_uint64 * 1536)()
     lib.stein_debug_dp_wg(wg)
-    w = np.array(list(wg), dtype=np.float64).reshape(256, 3)
+    w = np.array(list(wg), dtype=np.float64).reshape(256, 6)
     t0 = w[:, 0].min()
     life = (w[:, 1] - w[:, 0]) * 0.01
-    print("   last launch, by logical workgroup id (16 per line): end time us / strips of wave 0")
+    print("   last launch, by logical workgroup id (16 per line): own segments done > end (us) / wave 0's own + stolen strips")
     for k in range(0, 256, 16):
-        print("   %3d: " % k + " ".join("%5.0f/%-3d" % ((w[j, 1] - t0) * 0.01, w[j, 2]) for j in range(k, k + 16)))
+        print("   %3d: " % k + " ".join("%4.0f>%-4.0f/%2d+%-2d" % ((w[j, 4] - t0) * 0.01, (w[j, 1] - t0) * 0.01, w[j, 5], w[j, 2] - w[j, 5]) for j in range(k, k + 16)))
+    clk = w[:, 3] / np.maximum(w[:, 1] - w[:, 0], 1) * 0.1
+    print("   per XCD (32 logical ids each): mean end %s us | mean clock of wave 0 %s GHz" %
+          ([int(round(((w[32 * x:32 * x + 32, 1] - t0) * 0.01).mean())) for x in range(8)], [round(float(clk[32 * x:32 * x + 32].mean()), 3) for x in range(8)]))
+    lib.stein_debug_dp_slow.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    sl = (ctypes.c_uint64 * (8 * 2048))()
+    lib.stein_debug_dp_slow(sl)
+    S = np.array(list(sl), dtype=np.float64).reshape(2048, 8)
+    order = np.argsort(-S[:, 0])[:24]
+    print("   slowest strips (one per wave): wg.wave  cycles total = wait + mfma + requests + epilogue | segment strip | at us")
+    for o in order:
+        print("     %3d.%d  %8.0f = %7.0f + %7.0f + %7.0f + %7.0f | seg %3d strip %3d | %5.0f" % (o // 8, o % 8, S[o, 0], S[o, 1], S[o, 2], S[o, 3], S[o, 4], S[o, 5], S[o, 6], (S[o, 7] - t0) * 0.01))
+    print("   median over waves of the slowest strip: %.0f cycles" % np.median(S[S[:, 0] > 0, 0]))
+    print("   diagonal strips: %d, mean epilogue %.0f cycles" % (a[10], a[9] / max(a[10], 1)))
     print("   in-kernel clock %.3f GHz; mean wave lifetime %.1f us" % (a[7] / a[8] * 0.1, a[8] / waves * 0.01), flush=True)
 if world == 1:
     T = torch.randn(n, d, device=dev); G = torch.randn(n, d, device=dev)

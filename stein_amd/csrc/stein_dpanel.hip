@@ -40,12 +40,33 @@ constexpr int DP_PANEL = 16 * XPLANE;  // 128 KB: NP * ntk <= 16 planes of [128 
 constexpr int DP_LDS = DP_PANEL + 8 * DP_STAGE + 8 * DP_QBYTES;   // 157,696 of the 163,840 bytes
 constexpr int DP_SWITCH = 6;           // price of a panel switch in the balance, in strips
 
+// Who works on what.  A segment = one row tile's run of column strips = one operand panel.
+//   row block (not SYM): segment g = row tile g, strips [0, 4 tiles_n): all equally long.
+//   SYM: the rows of the triangle are folded into "virtual rows" of equal length: virtual row v = row v (strips [4 v, 4 N)),
+//        then row N - 1 - v (strips [4 (N - 1 - v), 4 N)): 4 N + 4 strips whatever v (the middle row of an odd N stands alone).
+//        Segment 2 v is the long part, 2 v + 1 the short one.
+// The workgroups form TEAMS of DP_TEAM (logical ids 4 t .. 4 t + 3); team t works through (virtual) rows t, t + teams, ... and
+// its 32 waves draw the strips of the current segment one by one from a counter in global memory, so the members of a team
+// advance along the columns together and finish together, whatever their speed.  Teams that share an XCD (xcd_remap: an XCD's
+// 32 workgroups = 8 teams) hold neighbouring (virtual) rows of equal length and therefore sweep the same column strips at
+// about the same time: one wave pulls a strip's operand into the XCD's L2, the others find it there.  (Dealt as contiguous
+// pieces of the plain row order, the triangle's rows shrink, the workgroups of an XCD drift apart along the columns, every
+// one of them streams alone from beyond the L2, and the XCDs holding the middle rows took 1.5 times as long as the others.)
+constexpr int DP_TEAM = 4;
+constexpr int DP_STEAL_MIN = 16;   // strips a segment must have left before a workgroup that has run out of work joins it
 template <bool SYM>
-__device__ __forceinline__ long dp_prefix(int I, int tiles_n) {   // cost of all rows above row tile I
-  return SYM ? 4l * ((long)I * tiles_n - (long)I * (I - 1) / 2) + (long)DP_SWITCH * I
-             : (long)I * (4l * tiles_n + DP_SWITCH);
+__device__ __forceinline__ int dp_segments(int tiles_m, int tiles_n) { return SYM ? 2 * ((tiles_n + 1) / 2) : tiles_m; }
+template <bool SYM>
+__device__ __forceinline__ void dp_segment(int g, int tiles_n, int& row, int& len) {
+  if (SYM) {
+    const int v = g >> 1;
+    row = (g & 1) ? tiles_n - 1 - v : v;
+    len = ((g & 1) && row == v) ? 0 : 4 * (tiles_n - row);   // (odd N: the middle row has no partner)
+  } else {
+    row = g;
+    len = 4 * tiles_n;
+  }
 }
-
 __device__ __forceinline__ const void* dp_uniform(const void* p) {   // make a wave-uniform pointer provably so
   const unsigned long long v = (unsigned long long)p;
   return reinterpret_cast<const void*>(
@@ -132,12 +153,12 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
                                                                   const float* __restrict__ r, float* __restrict__ D,
                                                                   int row0, int tiles_m, int tiles_n, long ldD,
                                                                   const float* __restrict__ two_s,
-                                                                  SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
+                                                                  SpecState* __restrict__ spec, u64* __restrict__ spec_buf,
+                                                                  u32* __restrict__ dealer /* [segments][STEIN_DP_DEALER_STRIDE], zeroed */) {
   constexpr int LPS = 2 * NP;                  // streamed loads per k tile: 2 column blocks x NP planes
   constexpr int W_LATE = 3 * LPS;              // the loads of the three k tiles behind the one waited for stay in flight
-  constexpr int W_EARLY = 3 * LPS + 16 + 2;    // ... and the 16 D stores and 2 norm loads issued between its request and its use
+  constexpr int W_EARLY = 3 * LPS + 16 + 3;    // ... and the 16 D stores, 2 norm loads and 1 draw issued between its request and its use
   __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS + 16];
-  u32* const dealer = reinterpret_cast<u32*>(smem + DP_LDS);   // the next strip of the segment nobody has taken yet
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   unsigned char* const panel = smem;
@@ -160,19 +181,11 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
 
   // ---- this workgroup's share of the strip order -----------------------------------------------------------------------
   const int G = gridDim.x, p = xcd_remap(blockIdx.x, G);
-  const long C = dp_prefix<SYM>(tiles_m, tiles_n);
-  const long c0 = C * p / G, c1 = C * (p + 1) / G;
-  int I = 0;
-  {
-    int lo = 0, hi = tiles_m;   // largest I with prefix(I) <= c0
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (dp_prefix<SYM>(mid, tiles_n) <= c0) lo = mid; else hi = mid;
-    }
-    I = lo;
-  }
+  const int teams = G / DP_TEAM, team = p / DP_TEAM;
+  const int nunit = SYM ? (tiles_n + 1) / 2 : tiles_m;   // virtual rows / rows
   // per-lane constants
   const u32 aoff = (u32)lane * 16u;                 // fragment byte of this lane
+  const u32 aoff1 = aoff + (u32)XPLANE;              // ... in the second plane
   const u32 roff = (u32)(lane >> 4) * 16u;          // norms of the 4 columns this lane holds in a 16-column block
   const int li = lane & 15, lq = lane >> 4;
   u32x4 ring[DP_RING][2][3];
@@ -180,12 +193,48 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   float ri[8];
   DP_STAMP_DECL;
 
-  for (; I < tiles_m && dp_prefix<SYM>(I, tiles_n) < c1; ++I) {
-    const long base = dp_prefix<SYM>(I, tiles_n) + DP_SWITCH;
-    const int len = SYM ? 4 * (tiles_n - I) : 4 * tiles_n;
-    const long sb_l = c0 - base, se_l = c1 - base;
-    const int sb = sb_l > 0 ? (int)sb_l : 0, se = se_l < len ? (int)se_l : len;
-    if (se <= sb) continue;
+  // The team's own segments first, in order; then the workgroup helps wherever most strips are left (wave 0 reads every
+  // segment's counter with one load per lane and picks the fullest): the XCDs of a launch finish up to 1.5x apart for
+  // reasons that are not in the work they were given (the slow ones run at the HIGHEST clock: they wait for memory; which
+  // ones are slow changes from launch to launch), and a team that is done early would otherwise sit out the rest.
+  const int nseg = dp_segments<SYM>(tiles_m, tiles_n);
+  int* const pick = reinterpret_cast<int*>(smem + DP_LDS);
+  int own_unit = p < teams * DP_TEAM ? team : nunit, own_half = 0;
+  for (;;) {
+    int g;
+    if (own_unit < nunit) {
+      g = SYM ? 2 * own_unit + own_half : own_unit;
+      if (SYM && own_half == 0) own_half = 1; else { own_half = 0; own_unit += teams; }
+    } else {
+      DP_STAMP_OWN_DONE;
+      __syncthreads();
+      if (w == 0) {
+        int best = -1, best_left = DP_STEAL_MIN - 1;
+        for (int base = 0; base < nseg; base += 64) {
+          const int gg = base + lane;
+          int left = -1;
+          if (gg < nseg) {
+            int Ig, lg;
+            dp_segment<SYM>(gg, tiles_n, Ig, lg);
+            left = lg - (int)__hip_atomic_load(dealer + (size_t)gg * STEIN_DP_DEALER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          int cand = gg;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {      // wave-wide arg max
+            const int l2 = __shfl_xor(left, o), c2 = __shfl_xor(cand, o);
+            if (l2 > left || (l2 == left && c2 < cand)) { left = l2; cand = c2; }
+          }
+          if (left > best_left) { best_left = left; best = cand; }
+        }
+        if (lane == 0) *pick = best;
+      }
+      __syncthreads();
+      g = *pick;
+      if (g < 0) break;
+    }
+    int I, len;
+    dp_segment<SYM>(g, tiles_n, I, len);
+    if (len == 0) continue;
     const int cfirst = SYM ? 4 * I : 0;            // first column strip of the row
     // ---- panel of row tile I -> LDS: wave w copies fragment w (1 KB) of every (k tile, plane) -------------------------
     __syncthreads();                               // everybody is done with the previous panel
@@ -208,43 +257,62 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
       // knows about) would sit in every strip's epilogue and drain the streamed loads in flight there
 #pragma unroll
       for (int ib = 0; ib < 8; ++ib) asm volatile("" : "+v"(ri[ib]));
-      if (t == 0) *dealer = (u32)(sb + 8);
     }
     __syncthreads();
     DP_STAMP(4);
 
-    // ---- the wave's strips: sb + w first, then whichever strip of the segment is next (an LDS counter deals them: at
-    // equal priority the older wave of a SIMD wins every issue arbitration and a static deal left the younger one to finish
-    // a quarter of its strips alone, with nothing to overlap its epilogues with) -------------------------------------------
-    int s = sb + w;
-    if (s < se) {
+    // ---- the wave's strips: drawn one at a time from the segment's counter, which the whole team shares.  A wave holds
+    // the strip it works on and the next one (whose operand it prefetches); the draw for the one after that is in flight.
+    // (Dealt statically the older wave of every SIMD, which wins each issue arbitration at equal priority, finished a
+    // quarter ahead of the younger one, which then ran its last strips alone with nothing to overlap its epilogues with.)
+    u32 first = 0u;
+    if (lane == 0) first = __hip_atomic_fetch_add(dealer + (size_t)g * STEIN_DP_DEALER_STRIDE, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int s = __builtin_amdgcn_readfirstlane((int)first), s1 = s + 1;
+    if (s < len) {
       auto strip_base = [&](int strip) {           // operand fragments of column strip `strip` (k tile 0, plane 0, block 0)
         const long j0 = 32l * (cfirst + strip);
         return reinterpret_cast<const u16*>(dp_uniform(T3 + ((size_t)(j0 >> 7) * ntk * 3) * XTILE_E + ((j0 & 127) >> 4) * 512));
       };
+      // The streamed memory operations are inline asm (neither counted nor waited for by the compiler, stein_x3_dev.h).  Each
+      // statement opens with s_nop 4: the compiler may have produced the statement's scalar base address with a VALU
+      // instruction a moment earlier (v_readfirstlane, or v_readlane when it reloads a spilled SGPR), and a vector-memory
+      // instruction that reads such an SGPR within 5 wait states sees its OLD value -- which the compiler pads for its own
+      // instructions but cannot for the inside of an asm statement (cdna_hip_programming.md 5.7 item 2; found the hard way:
+      // a diagnostic build with more SGPR pressure sent its atomics to address 0).
       auto request = [&](const u16* sbase, int kt, u32x4 (&slot)[2][3]) {
         const u16* src = sbase + (size_t)(kt < ntk ? kt : ntk - 1) * 3 * XTILE_E;   // past the end: a harmless re-read keeps the counts
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-          for (int pl = 0; pl < NP; ++pl) stream_load16(slot[jb][pl], src, aoff + (u32)(jb * 1024 + pl * XPLANE));
+        if constexpr (NP == 2) {
+          asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %5, %6\n\t"
+                       "global_load_dwordx4 %2, %4, %6 offset:1024\n\tglobal_load_dwordx4 %3, %5, %6 offset:1024"
+                       : "=&v"(slot[0][0]), "=&v"(slot[0][1]), "=&v"(slot[1][0]), "=&v"(slot[1][1])
+                       : "v"(aoff), "v"(aoff1), "s"(src));
+        } else {
+          asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                       : "=&v"(slot[0][0]), "=&v"(slot[1][0]) : "v"(aoff), "s"(src));
+        }
       };
       auto request_norms = [&](int strip) {
         const float* rb = reinterpret_cast<const float*>(dp_uniform(r + 32l * (cfirst + strip)));
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rj[0]) : "v"(roff), "s"(rb) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(rj[1]) : "v"(roff), "s"(rb) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:64"
+                     : "=&v"(rj[0]), "=&v"(rj[1]) : "v"(roff), "s"(rb) : "memory");
+      };
+      u32 pend = 0u;                               // the draw in flight: lane 0 receives the strip after s1
+      const u32* ctr = reinterpret_cast<const u32*>(dp_uniform(dealer + (size_t)g * STEIN_DP_DEALER_STRIDE));
+      auto draw = [&]() {                          // one more streamed memory operation, counted like the loads
+        const u32 one = 1u, zero = 0u;
+        if (lane == 0)
+          asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(pend) : "v"(zero), "v"(one), "s"(ctr) : "memory");
       };
       const u16* cur = strip_base(s);
       request_norms(s);
 #pragma unroll
       for (int u = 0; u < DP_RING; ++u) request(cur, u, ring[u]);
-      bool regular = false;                        // the previous epilogue issued exactly 16 stores + 2 norm loads
+      draw();
+      bool regular = false;                        // the previous epilogue issued exactly 16 stores + 2 norm loads + 1 draw
       for (;;) {
-        u32 drawn = 0u;
-        if (lane == 0) drawn = __hip_atomic_fetch_add(dealer, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int sdrawn = __builtin_amdgcn_readfirstlane((int)drawn);
-        const bool more = sdrawn < se;
-        const int snext = more ? sdrawn : s;       // (no next strip: the trailing requests re-read this one)
+        DP_STRIP_BEGIN;
+        const bool more = s1 < len;
+        const int snext = more ? s1 : s;           // (no next strip: the trailing requests re-read this one)
         const u16* nxt = strip_base(snext);
         f32x4 acc[8][2];
 #pragma unroll
@@ -257,17 +325,25 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
           for (int u = 0; u < DP_RING; ++u) {
             const int kt = g * DP_RING + u;
             DP_STAMP(2);
-            if (g == 0 && regular) stream_wait<W_EARLY>(); else stream_wait<W_LATE>();
+            // (the looser wait first, unconditionally: every path from a request to its use then passes a wait, which is
+            // what stein_amd/csrc/isa_check.py verifies on the assembly)
+            stream_wait<W_EARLY>();
+            if (!(g == 0 && regular)) stream_wait<W_LATE>();
             DP_STAMP(0);
             if (kt < ntk) dp_step<NP>(panel + kt * NP * XPLANE + aoff, ring[u], acc);
             DP_STAMP(1);
             request(last ? nxt : cur, last ? u : kt + DP_RING, ring[u]);
           }
         }
-        // the strip's column norms were requested a whole k loop ago; with more than one group of k tiles the loop's own
-        // waits have covered them, with a single group only the 4 requests of this loop are younger
+        // the strip's column norms and the pending draw were requested a whole k loop ago: everything but the last four
+        // requests of this loop is older than they are (with more than one group of k tiles the loop's own waits have covered
+        // them already and this one costs nothing)
         DP_STAMP(2);
-        if (groups == 1) stream_wait<DP_RING * LPS>();
+        stream_wait<DP_RING * LPS>();
+        // the draw issued behind the previous epilogue has landed (it is older than everything this k loop waited for);
+        // the empty statement ties its use to this point of the program
+        asm volatile("" : "+v"(pend) :: "memory");
+        const int s2 = __builtin_amdgcn_readfirstlane((int)pend);
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
         const int c32 = cfirst + s;
         float* __restrict__ dt = D + ((size_t)I * ntc + c32) * DT_ELEMS;
@@ -278,6 +354,8 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         const int d4 = c32 & 3;
         float* __restrict__ dmir = D + ((size_t)I * ntc + 4 * I) * DT_ELEMS;      // the diagonal tile's first 32 columns
         const int sr = lane >> 3, sc4 = (lane & 7) * 4;                          // staged row / first column of this lane
+        const int lane_dir = sr * 32 + sc4, lane_dij = sr - sc4;                  // (staged-row layout: direct stores)
+        const int lane_mir = lq * 128 + li, lane_dji = 4 * lq - li;               // (accumulator layout: mirror stores)
 #pragma unroll
         for (int ib = 0; ib < 8; ++ib) {
 #pragma unroll
@@ -287,24 +365,41 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[ib][jb][e], nts, ri[ib] + rj[jb][e]);
             if (window && !diag) { const u32 w4[4] = {wt, wt, wt, wt}; dp_count4<true>(sx, v, w4, wt, lane); }
             *reinterpret_cast<float4*>(stg + li * DP_PITCH + jb * 64 + lq * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            if (diag && ib < 2 * d4 + 2) {
+              // mirror places, straight from the accumulator layout: lane = row i, so the 16 lanes of a quarter wave write 64
+              // contiguous bytes of mirror row j.  (From the staged rows, where neighbouring lanes hold neighbouring COLUMNS,
+              // every lane's 4 bytes were a memory transaction of their own: ~8000 per strip, ~150 us, during which the
+              // other waves of the CU could not issue their loads either.)
+              const int dji = 32 * d4 + 16 * jb - 16 * ib + lane_dji;               // j - i at e = 0
+              float* __restrict__ pm = dmir + (size_t)(ib >> 1) * DT_ELEMS + (d4 * 32 + jb * 16) * 32 + ((16 * ib) & 31);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (dji + e > 0) pm[lane_mir + e * 32] = v[e];
+            }
           }
           const float4 x0 = *reinterpret_cast<const float4*>(stg + sr * DP_PITCH + sc4 * 4);
           const float4 x1 = *reinterpret_cast<const float4*>(stg + (8 + sr) * DP_PITCH + sc4 * 4);
           if (!diag) {
-            *reinterpret_cast<float4*>(dt + ib * 512 + lane * 4) = x0;          // rows 16 ib .. + 7: 1 KB contiguous
-            *reinterpret_cast<float4*>(dt + ib * 512 + 256 + lane * 4) = x1;    // rows 16 ib + 8 .. + 15
+            DP_STORE16(dt + ib * 512 + lane * 4, x0);          // rows 16 ib .. + 7: 1 KB contiguous
+            DP_STORE16(dt + ib * 512 + 256 + lane * 4, x1);    // rows 16 ib + 8 .. + 15
           } else if (ib < 2 * d4 + 2) {                                          // (blocks below the diagonal block: nothing)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const float xs[4] = {h ? x1.x : x0.x, h ? x1.y : x0.y, h ? x1.z : x0.z, h ? x1.w : x0.w};
-              const int i = 16 * ib + 8 * h + sr;                                // row inside the tile
+              // row i = i0 + sr and column j = 32 d4 + sc4 + e inside the tile; everything but lane_dir / dij is
+              // wave-uniform (addresses written out this way keep the diagonal path to a handful of registers)
+              const int i0 = 16 * ib + 8 * h;
+              float* __restrict__ pd = dt + i0 * 32;
+              const int dij = i0 - 32 * d4 + lane_dij;                           // i - j at e = 0
               u32 w4[4];
+              // the lane's four columns lie all above the diagonal (one 16-byte store, as everywhere else), all below it
+              // (nothing), or straddle it (entry by entry; a handful of lanes).  Sixty-four single-entry stores 16 bytes apart
+              // per instruction made a diagonal strip take ~100 us: the waves that drew them held up their whole team.
+              if (dij < 0) *reinterpret_cast<float4*>(pd + lane_dir) = make_float4(xs[0], xs[1], xs[2], xs[3]);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const int j = 32 * d4 + sc4 + e;                                 // column inside the tile
-                w4[e] = i < j ? 2u : (i == j ? 1u : 0u);
-                if (w4[e]) dt[i * 32 + sc4 + e] = xs[e];
-                if (w4[e] == 2u) dmir[(size_t)(i >> 5) * DT_ELEMS + j * 32 + (i & 31)] = xs[e];
+                w4[e] = dij < e ? 2u : (dij == e ? 1u : 0u);
+                if (w4[e] && dij >= 0) pd[lane_dir + e] = xs[e];
               }
               if (window) dp_count4<false>(sx, xs, w4, 0u, lane);
             }
@@ -313,11 +408,14 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         regular = !diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
         request_norms(snext);                      // ("memory": the strip's stores are issued before this point)
+        draw();
         cur = nxt;
-        DP_STAMP(3);
+        if (diag) { DP_STAMP(6); DP_STAMP_COUNT(7); } else DP_STAMP(3);
         DP_STAMP_COUNT(5);
+        DP_STRIP_END(g, s);
         if (!more) break;
-        s = snext;
+        s = s1;
+        s1 = s2;
       }
       stream_wait<0>();                            // the trailing re-reads land before their registers move on
     }
@@ -325,6 +423,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   }
   DP_STAMP_FLUSH(lane);
   DP_STAMP_WG(p, w, lane);
+  DP_SLOW_FLUSH(p, w, lane);
   if (window) {
     dp_flush(sx, spec, spec_buf, lane);
     if (lane == 0) {
@@ -345,6 +444,7 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
   if (level0_only) return false;                                   // the caller wants the level-0 histogram from the epilogue
   if ((n & 127) || (n_local & 127) || (row0 & 127)) return false;
   if (np * ntk > 16) return false;                                 // the panel must fit 128 KB of LDS
+  if ((n_local / 128 > n / 128 ? n_local / 128 : n / 128) + 1 > STEIN_DP_DEALER_WORDS) return false;   // one counter per segment
   // below ~16 strips per wave the panel loads and the ragged tail outweigh the overlap (and the launch fits one
   // round of the tile kernel anyway)
   return any_size || (n_local / 128) * (n / 32) >= 256 * 8 * 8;
@@ -364,7 +464,12 @@ int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, c
     HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     ncu = v > 0 ? v : 256;
   }
-#define DP_LAUNCH(SYM, NP) hipLaunchKernelGGL((k_distance_panel<SYM, NP>), dim3((unsigned)ncu), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf)
+  // the segment counters the teams draw from (behind the scales in the PLANES section), zero at launch
+  u32* dealer = reinterpret_cast<u32*>(const_cast<char*>(planes) + L.x3_dealer);
+  const int nseg = symmetric ? 2 * ((tiles_n + 1) / 2) : tiles_m;
+  HIP_TRY(hipMemsetAsync(dealer, 0, (size_t)nseg * STEIN_DP_DEALER_STRIDE * sizeof(u32), stream));
+  const int grid = ncu / DP_TEAM * DP_TEAM;
+#define DP_LAUNCH(SYM, NP) hipLaunchKernelGGL((k_distance_panel<SYM, NP>), dim3((unsigned)grid), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf, dealer)
   if (stein_x3_kind(dtype) == 1) { if (symmetric) DP_LAUNCH(true, 1); else DP_LAUNCH(false, 1); }
   else { if (symmetric) DP_LAUNCH(true, 2); else DP_LAUNCH(false, 2); }
 #undef DP_LAUNCH

@@ -626,10 +626,16 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     auto wait_loads = [&](int v, f32x4g (&rd)[PR]) {
       const int later = ntile - v - 1;
       (void)rd;
-      if (later >= 3) stream_wait<3 * PR>();
-      else if (later == 2) stream_wait<2 * PR>();
-      else if (later == 1) stream_wait<PR>();
-      else stream_wait<0>();
+      // (nested, the loosest wait first and unconditional: every path from a request to its use passes a wait, which is
+      // what stein_amd/csrc/isa_check.py verifies on the assembly)
+      stream_wait<3 * PR>();
+      if (later < 3) {
+        stream_wait<2 * PR>();
+        if (later < 2) {
+          stream_wait<PR>();
+          if (later < 1) stream_wait<0>();
+        }
+      }
     };
     // registers of tile j0 -> LDS stage `buf`
     // One k tile: 16 entries per thread, done phase by phase over all 16 (fma, exp, row sums, hi terms, residuals, lo
@@ -876,8 +882,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // been requested already and stay in flight
     auto wait_b = [&](bool younger, u32x4 (&b)[CJ][3]) {
       (void)b;
-      if (younger) stream_wait<CJ * NP>();
-      else stream_wait<0>();
+      stream_wait<CJ * NP>();
+      if (!younger) stream_wait<0>();
     };
     // A fragments are read one 16-row block ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
     // all 24 reads (96 registers) to the top of the tile

@@ -1083,7 +1083,11 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
   if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW | STEIN_FLAG_TILE_DISTANCE)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+#ifdef STEIN_LD_PAD   // (experiment builds: extra column tiles per row block of the distance image)
+  L->ld_dist = (int64_t)align_up((size_t)n, 64) + STEIN_LD_PAD;
+#else
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
+#endif
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
   // workgroups per unit of split and resident workgroups per round: the fp32 kernel tiles [G | theta] in 128-column
@@ -1152,7 +1156,8 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   L->x3_gt3 = t3 + tt3;
   L->x3_sc = t3 + 2 * tt3;   // scales area: float[4 dc + 4] + u32[2 dc]
   const size_t scb = align_up((size_t)(6 * L->x3_dc + 4) * 4, 256);
-  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 + scb : 0);
+  L->x3_dealer = t3 + 2 * tt3 + scb;
+  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 + scb + (size_t)STEIN_DP_DEALER_WORDS * STEIN_DP_DEALER_STRIDE * 4 : 0);
   L->total = at;
   return STEIN_OK;
 }
