@@ -549,9 +549,6 @@ __device__ __forceinline__ void phi_epilogue(const f32x16 (&acc)[2][2], const fl
 }
 
 // ---- host-side layout (shared by both translation units) -----------------------------------------------
-constexpr int STEIN_DP_DEALER_WORDS = 2048;   // segment counters of the panel-resident distance kernel ...
-constexpr int STEIN_DP_DEALER_STRIDE = 64;    // ... one per 256 bytes: atomics are served per memory channel, and all teams
-                                              // drawing from counters packed into four cache lines stalled each other's loads
 struct SteinLayout {
   size_t off[STEIN_WS_NSECTIONS];
   size_t total;
@@ -562,7 +559,6 @@ struct SteinLayout {
   int64_t x3_dc, x3_nk;     // transposed planes of theta and of the score: x3_dc x x3_nk  (contraction B operand)
   size_t x3_t3, x3_tt3, x3_gt3;  // byte offsets inside the PLANES section
   size_t x3_sc;                  // power-of-two operand scales (stein_x3.hip: "scales area"), inside the PLANES section
-  size_t x3_dealer;              // u32 [STEIN_DP_DEALER_WORDS][STEIN_DP_DEALER_STRIDE]: segment counters of the panel-resident distance kernel
 };
 int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flags, SteinLayout* L);
 

@@ -45,15 +45,16 @@ constexpr int DP_SWITCH = 6;           // price of a panel switch in the balance
 //   SYM: the rows of the triangle are folded into "virtual rows" of equal length: virtual row v = row v (strips [4 v, 4 N)),
 //        then row N - 1 - v (strips [4 (N - 1 - v), 4 N)): 4 N + 4 strips whatever v (the middle row of an odd N stands alone).
 //        Segment 2 v is the long part, 2 v + 1 the short one.
-// The workgroups form TEAMS of DP_TEAM (logical ids 4 t .. 4 t + 3); team t works through (virtual) rows t, t + teams, ... and
-// its 32 waves draw the strips of the current segment one by one from a counter in global memory, so the members of a team
-// advance along the columns together and finish together, whatever their speed.  Teams that share an XCD (xcd_remap: an XCD's
-// 32 workgroups = 8 teams) hold neighbouring (virtual) rows of equal length and therefore sweep the same column strips at
-// about the same time: one wave pulls a strip's operand into the XCD's L2, the others find it there.  (Dealt as contiguous
-// pieces of the plain row order, the triangle's rows shrink, the workgroups of an XCD drift apart along the columns, every
-// one of them streams alone from beyond the L2, and the XCDs holding the middle rows took 1.5 times as long as the others.)
-constexpr int DP_TEAM = 4;
-constexpr int DP_STEAL_MIN = 16;   // strips a segment must have left before a workgroup that has run out of work joins it
+// A workgroup takes a contiguous, equally priced piece of this order (a panel switch is priced in), and workgroups that
+// share an XCD take neighbouring pieces (xcd_remap).  With equally long (virtual) rows, workgroup p and workgroup
+// p + (workgroups per row) sit at the same place of neighbouring rows and stream the same column strips at the same time:
+// one of them pulls a strip's operand into the XCD's L2, the others find it there.  (Dealt in plain row order the
+// triangle's rows shrink, the workgroups of an XCD drift apart along the columns, every one of them streams alone from
+// beyond the L2, and the XCDs holding the middle rows took 1.5 times as long as the others.)  Inside a workgroup the strips
+// of a piece are dealt to the waves one by one by a counter in LDS.
+// (Tried and dropped, round 3: teams of four workgroups per virtual row drawing strips from a counter in global memory,
+// with work stealing once a team had run dry -- 0.206-0.219 ms at C3 against 0.192 for this form on like boxes; what holds
+// a launch up is not the deal but its D stores, see DESIGN.md.)
 template <bool SYM>
 __device__ __forceinline__ int dp_segments(int tiles_m, int tiles_n) { return SYM ? 2 * ((tiles_n + 1) / 2) : tiles_m; }
 template <bool SYM>
@@ -67,6 +68,20 @@ __device__ __forceinline__ void dp_segment(int g, int tiles_n, int& row, int& le
     len = 4 * tiles_n;
   }
 }
+template <bool SYM>
+__device__ __forceinline__ long dp_prefix(int g, int tiles_n) {   // price of all segments before segment g
+  if (!SYM) return (long)g * (4l * tiles_n + DP_SWITCH);
+  const int v = g >> 1;
+  return (long)v * (4l * tiles_n + 4 + 2 * DP_SWITCH) + ((g & 1) ? DP_SWITCH + 4l * (tiles_n - v) : 0l);
+}
+template <bool SYM>
+__device__ __forceinline__ long dp_total(int tiles_m, int tiles_n) {
+  const int ng = dp_segments<SYM>(tiles_m, tiles_n);
+  int row, len;
+  dp_segment<SYM>(ng - 1, tiles_n, row, len);
+  return dp_prefix<SYM>(ng - 1, tiles_n) + (len ? len + DP_SWITCH : 0);
+}
+
 __device__ __forceinline__ const void* dp_uniform(const void* p) {   // make a wave-uniform pointer provably so
   const unsigned long long v = (unsigned long long)p;
   return reinterpret_cast<const void*>(
@@ -153,11 +168,10 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
                                                                   const float* __restrict__ r, float* __restrict__ D,
                                                                   int row0, int tiles_m, int tiles_n, long ldD,
                                                                   const float* __restrict__ two_s,
-                                                                  SpecState* __restrict__ spec, u64* __restrict__ spec_buf,
-                                                                  u32* __restrict__ dealer /* [segments][STEIN_DP_DEALER_STRIDE], zeroed */) {
+                                                                  SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
   constexpr int LPS = 2 * NP;                  // streamed loads per k tile: 2 column blocks x NP planes
   constexpr int W_LATE = 3 * LPS;              // the loads of the three k tiles behind the one waited for stay in flight
-  constexpr int W_EARLY = 3 * LPS + 16 + 3;    // ... and the 16 D stores, 2 norm loads and 1 draw issued between its request and its use
+  constexpr int W_EARLY = 3 * LPS + 16 + 2;    // ... and the 16 D stores and 2 norm loads issued between its request and its use
   __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS + 16];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -181,8 +195,19 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
 
   // ---- this workgroup's share of the strip order -----------------------------------------------------------------------
   const int G = gridDim.x, p = xcd_remap(blockIdx.x, G);
-  const int teams = G / DP_TEAM, team = p / DP_TEAM;
-  const int nunit = SYM ? (tiles_n + 1) / 2 : tiles_m;   // virtual rows / rows
+  const int nseg = dp_segments<SYM>(tiles_m, tiles_n);
+  const long C = dp_total<SYM>(tiles_m, tiles_n);
+  const long c0 = C * p / G, c1 = C * (p + 1) / G;
+  int g = 0;
+  {
+    int lo = 0, hi = nseg;   // largest g with prefix(g) <= c0
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (dp_prefix<SYM>(mid, tiles_n) <= c0) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  u32* const dealer = reinterpret_cast<u32*>(smem + DP_LDS);   // the next strip of the piece nobody has taken yet
   // per-lane constants
   const u32 aoff = (u32)lane * 16u;                 // fragment byte of this lane
   const u32 aoff1 = aoff + (u32)XPLANE;              // ... in the second plane
@@ -193,48 +218,13 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   float ri[8];
   DP_STAMP_DECL;
 
-  // The team's own segments first, in order; then the workgroup helps wherever most strips are left (wave 0 reads every
-  // segment's counter with one load per lane and picks the fullest): the XCDs of a launch finish up to 1.5x apart for
-  // reasons that are not in the work they were given (the slow ones run at the HIGHEST clock: they wait for memory; which
-  // ones are slow changes from launch to launch), and a team that is done early would otherwise sit out the rest.
-  const int nseg = dp_segments<SYM>(tiles_m, tiles_n);
-  int* const pick = reinterpret_cast<int*>(smem + DP_LDS);
-  int own_unit = p < teams * DP_TEAM ? team : nunit, own_half = 0;
-  for (;;) {
-    int g;
-    if (own_unit < nunit) {
-      g = SYM ? 2 * own_unit + own_half : own_unit;
-      if (SYM && own_half == 0) own_half = 1; else { own_half = 0; own_unit += teams; }
-    } else {
-      DP_STAMP_OWN_DONE;
-      __syncthreads();
-      if (w == 0) {
-        int best = -1, best_left = DP_STEAL_MIN - 1;
-        for (int base = 0; base < nseg; base += 64) {
-          const int gg = base + lane;
-          int left = -1;
-          if (gg < nseg) {
-            int Ig, lg;
-            dp_segment<SYM>(gg, tiles_n, Ig, lg);
-            left = lg - (int)__hip_atomic_load(dealer + (size_t)gg * STEIN_DP_DEALER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          int cand = gg;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {      // wave-wide arg max
-            const int l2 = __shfl_xor(left, o), c2 = __shfl_xor(cand, o);
-            if (l2 > left || (l2 == left && c2 < cand)) { left = l2; cand = c2; }
-          }
-          if (left > best_left) { best_left = left; best = cand; }
-        }
-        if (lane == 0) *pick = best;
-      }
-      __syncthreads();
-      g = *pick;
-      if (g < 0) break;
-    }
+  for (; g < nseg && dp_prefix<SYM>(g, tiles_n) < c1; ++g) {
     int I, len;
     dp_segment<SYM>(g, tiles_n, I, len);
-    if (len == 0) continue;
+    const long base = dp_prefix<SYM>(g, tiles_n) + DP_SWITCH;
+    const long sb_l = c0 - base, se_l = c1 - base;
+    const int sb = sb_l > 0 ? (int)sb_l : 0, se = se_l < len ? (int)se_l : len;
+    if (se <= sb) continue;
     const int cfirst = SYM ? 4 * I : 0;            // first column strip of the row
     // ---- panel of row tile I -> LDS: wave w copies fragment w (1 KB) of every (k tile, plane) -------------------------
     __syncthreads();                               // everybody is done with the previous panel
@@ -257,18 +247,17 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
       // knows about) would sit in every strip's epilogue and drain the streamed loads in flight there
 #pragma unroll
       for (int ib = 0; ib < 8; ++ib) asm volatile("" : "+v"(ri[ib]));
+      if (t == 0) *dealer = (u32)(sb + 16);
     }
     __syncthreads();
     DP_STAMP(4);
 
-    // ---- the wave's strips: drawn one at a time from the segment's counter, which the whole team shares.  A wave holds
-    // the strip it works on and the next one (whose operand it prefetches); the draw for the one after that is in flight.
-    // (Dealt statically the older wave of every SIMD, which wins each issue arbitration at equal priority, finished a
-    // quarter ahead of the younger one, which then ran its last strips alone with nothing to overlap its epilogues with.)
-    u32 first = 0u;
-    if (lane == 0) first = __hip_atomic_fetch_add(dealer + (size_t)g * STEIN_DP_DEALER_STRIDE, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int s = __builtin_amdgcn_readfirstlane((int)first), s1 = s + 1;
-    if (s < len) {
+    // ---- the wave's strips: sb + w and sb + 8 + w first, then whichever strip of the piece is next (a counter in LDS deals
+    // them: at equal priority the older wave of a SIMD wins every issue arbitration, and dealt statically the younger one
+    // was left to finish a quarter of its strips alone, with nothing to overlap its epilogues with).  A wave holds the strip
+    // it works on and the next one, whose operand it prefetches.
+    int s = sb + w, s1 = sb + 8 + w;
+    if (s < se) {
       auto strip_base = [&](int strip) {           // operand fragments of column strip `strip` (k tile 0, plane 0, block 0)
         const long j0 = 32l * (cfirst + strip);
         return reinterpret_cast<const u16*>(dp_uniform(T3 + ((size_t)(j0 >> 7) * ntk * 3) * XTILE_E + ((j0 & 127) >> 4) * 512));
@@ -296,22 +285,17 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:64"
                      : "=&v"(rj[0]), "=&v"(rj[1]) : "v"(roff), "s"(rb) : "memory");
       };
-      u32 pend = 0u;                               // the draw in flight: lane 0 receives the strip after s1
-      const u32* ctr = reinterpret_cast<const u32*>(dp_uniform(dealer + (size_t)g * STEIN_DP_DEALER_STRIDE));
-      auto draw = [&]() {                          // one more streamed memory operation, counted like the loads
-        const u32 one = 1u, zero = 0u;
-        if (lane == 0)
-          asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(pend) : "v"(zero), "v"(one), "s"(ctr) : "memory");
-      };
       const u16* cur = strip_base(s);
       request_norms(s);
 #pragma unroll
       for (int u = 0; u < DP_RING; ++u) request(cur, u, ring[u]);
-      draw();
-      bool regular = false;                        // the previous epilogue issued exactly 16 stores + 2 norm loads + 1 draw
+      bool regular = false;                        // the previous epilogue issued exactly 16 stores + 2 norm loads
       for (;;) {
         DP_STRIP_BEGIN;
-        const bool more = s1 < len;
+        u32 drawn = 0u;                            // the strip after s1
+        if (lane == 0) drawn = __hip_atomic_fetch_add(dealer, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int s2 = __builtin_amdgcn_readfirstlane((int)drawn);
+        const bool more = s1 < se;
         const int snext = more ? s1 : s;           // (no next strip: the trailing requests re-read this one)
         const u16* nxt = strip_base(snext);
         f32x4 acc[8][2];
@@ -335,15 +319,11 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
             request(last ? nxt : cur, last ? u : kt + DP_RING, ring[u]);
           }
         }
-        // the strip's column norms and the pending draw were requested a whole k loop ago: everything but the last four
-        // requests of this loop is older than they are (with more than one group of k tiles the loop's own waits have covered
-        // them already and this one costs nothing)
+        // the strip's column norms were requested a whole k loop ago: everything but the last four requests of this loop is
+        // younger than they are (with more than one group of k tiles the loop's own waits have covered them already and
+        // this one costs nothing)
         DP_STAMP(2);
         stream_wait<DP_RING * LPS>();
-        // the draw issued behind the previous epilogue has landed (it is older than everything this k loop waited for);
-        // the empty statement ties its use to this point of the program
-        asm volatile("" : "+v"(pend) :: "memory");
-        const int s2 = __builtin_amdgcn_readfirstlane((int)pend);
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
         const int c32 = cfirst + s;
         float* __restrict__ dt = D + ((size_t)I * ntc + c32) * DT_ELEMS;
@@ -408,7 +388,6 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         regular = !diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
         request_norms(snext);                      // ("memory": the strip's stores are issued before this point)
-        draw();
         cur = nxt;
         if (diag) { DP_STAMP(6); DP_STAMP_COUNT(7); } else DP_STAMP(3);
         DP_STAMP_COUNT(5);
@@ -444,7 +423,6 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
   if (level0_only) return false;                                   // the caller wants the level-0 histogram from the epilogue
   if ((n & 127) || (n_local & 127) || (row0 & 127)) return false;
   if (np * ntk > 16) return false;                                 // the panel must fit 128 KB of LDS
-  if ((n_local / 128 > n / 128 ? n_local / 128 : n / 128) + 1 > STEIN_DP_DEALER_WORDS) return false;   // one counter per segment
   // below ~16 strips per wave the panel loads and the ragged tail outweigh the overlap (and the launch fits one
   // round of the tile kernel anyway)
   return any_size || (n_local / 128) * (n / 32) >= 256 * 8 * 8;
@@ -464,12 +442,7 @@ int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, c
     HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     ncu = v > 0 ? v : 256;
   }
-  // the segment counters the teams draw from (behind the scales in the PLANES section), zero at launch
-  u32* dealer = reinterpret_cast<u32*>(const_cast<char*>(planes) + L.x3_dealer);
-  const int nseg = symmetric ? 2 * ((tiles_n + 1) / 2) : tiles_m;
-  HIP_TRY(hipMemsetAsync(dealer, 0, (size_t)nseg * STEIN_DP_DEALER_STRIDE * sizeof(u32), stream));
-  const int grid = ncu / DP_TEAM * DP_TEAM;
-#define DP_LAUNCH(SYM, NP) hipLaunchKernelGGL((k_distance_panel<SYM, NP>), dim3((unsigned)grid), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf, dealer)
+#define DP_LAUNCH(SYM, NP) hipLaunchKernelGGL((k_distance_panel<SYM, NP>), dim3((unsigned)ncu), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf)
   if (stein_x3_kind(dtype) == 1) { if (symmetric) DP_LAUNCH(true, 1); else DP_LAUNCH(false, 1); }
   else { if (symmetric) DP_LAUNCH(true, 2); else DP_LAUNCH(false, 2); }
 #undef DP_LAUNCH

@@ -1156,8 +1156,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   L->x3_gt3 = t3 + tt3;
   L->x3_sc = t3 + 2 * tt3;   // scales area: float[4 dc + 4] + u32[2 dc]
   const size_t scb = align_up((size_t)(6 * L->x3_dc + 4) * 4, 256);
-  L->x3_dealer = t3 + 2 * tt3 + scb;
-  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 + scb + (size_t)STEIN_DP_DEALER_WORDS * STEIN_DP_DEALER_STRIDE * 4 : 0);
+  put(STEIN_WS_PLANES, (flags & STEIN_FLAG_X3) ? t3 + 2 * tt3 + scb : 0);
   L->total = at;
   return STEIN_OK;
 }
