@@ -269,7 +269,7 @@ class SvgdEngine:
         # the fused call takes the one-kernel path for this shape (stein_small.hip: n <= 160): no distance image exists.
         # The layout tells: only then is the SPEC section of the workspace empty (stein_make_layout)
         self._one_kernel = (not self.sharded) and offs[_lib.WS_PLANES] == offs[_lib.WS_SPEC]
-        self._have_dist = False
+        self._have_dist = not self._one_kernel   # (a caller that drives the staged calls on this engine's buffers gets an image too)
         self._flags_host = None      # page-locked landing place of the window's hit flag (HIP stages, window form)
         self._flags_event = None
         if comm not in ("auto", "native", "torch"):
@@ -353,8 +353,8 @@ class SvgdEngine:
         """Row-major [n_local, n] copy of the distance block (de-tiled; for inspection and tests).  After a single-rank
         step on the split path only the tiles on and above the diagonal are stored; the rest is mirrored in here."""
         if not self._have_dist:
-            raise RuntimeError("no distance image: nothing has run yet, or the last step took the one-kernel path "
-                               "(n <= 160), which keeps D in LDS; build the engine with small=False to get one")
+            raise RuntimeError("no distance image: this engine's fused call takes the one-kernel path (n <= 160), which "
+                               "keeps D in LDS; build the engine with small=False to get one")
         return untile_distances(self.dist, self.n_local, self.n, upper=self.dist_upper)
 
     @property
