@@ -111,7 +111,8 @@ def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
     return float((diff.norm() / ref.norm()).item()), len(rows)
 
 
-def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clock_stages=True, x3=None, window=True):
+def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clock_stages=True, x3=None, window=True,
+                 comm="torch", tile_distance=False):
     from stein_amd import _lib
     from stein_amd.engine import SvgdEngine
     from stein_amd.optimizers import AdagradGradientDescent
@@ -120,23 +121,19 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     row0 = rank * n_local
     T64, G64, theta, G = make_inputs(n, d, row0, n_local, device, torch)
     bf16 = bool(wl.get("bf16"))      # BASELINE config 2: the kernels see bf16 theta / score; theta's master copy stays fp32
-    ekw = dict(device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32, x3=x3, window=window)
+    ekw = dict(device=device, group=group, dtype=torch.bfloat16 if bf16 else torch.float32, x3=x3, window=window,
+               tile_distance=tile_distance)
     comm_note = None
     if world > 1:
-        # the library's own RCCL communicator (the step is one C call); every rank must take the same path, so the
-        # ranks agree on whether all of them got a communicator and otherwise all use torch.distributed's collectives
+        # who issues the collectives: torch.distributed over RCCL (default: the path every multi-rank test has run) or the
+        # library's own RCCL communicator (--comm native; its set-up is collective-safe: it fails on every rank or on none)
         try:
-            eng = SvgdEngine(n, d, comm="native", **ekw)
-            ok, why = 1, ""
-        except Exception as exc:      # noqa: BLE001 -- reported in the JSON line, never silent
-            eng, ok, why = None, 0, "%s: %s" % (type(exc).__name__, exc)
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) == 0:
-            if eng is not None:
-                eng.close()
+            eng = SvgdEngine(n, d, comm=comm, **ekw)
+        except RuntimeError as exc:
+            if comm != "native":
+                raise
             eng = SvgdEngine(n, d, comm="torch", **ekw)
-            comm_note = "library communicator unavailable on some rank (%s): torch.distributed collectives" % (why or "other rank")
+            comm_note = "library communicator unavailable (%s): torch.distributed collectives" % exc
     else:
         eng = SvgdEngine(n, d, **ekw)
     gd = AdagradGradientDescent(learning_rate=1e-3, alpha=0.9)
@@ -214,44 +211,163 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
         T_all, G_all = cur.float(), G.float()
     relerr, nrows = parity_sample(torch, T_all, G_all, phi, row0, float(eng.h2.item()))
     crosscheck = None
-    if world > 1 and eng.comm == "native":
-        # the same step with torch.distributed issuing the collectives between the rank segments: same kernels, same
-        # data, so phi and the bandwidth must come out bit-identical (|phi|^2 to the order of its fp64 rank sum)
-        phi_native, h2_native, sq_native = phi.clone(), float(eng.h2.item()), float(eng.sqnorm.item())
-        other = SvgdEngine(n, d, comm="torch", **ekw)
-        other.ws[other._offs[_lib.WS_SELECT]:other._offs[_lib.WS_SELECT] + _lib.SELECT_BYTES].copy_(
-            eng.ws[eng._offs[_lib.WS_SELECT]:eng._offs[_lib.WS_SELECT] + _lib.SELECT_BYTES])
-        phi_torch = other.compute_phi(cur, G)
-        torch.cuda.synchronize(device)
-        crosscheck = dict(phi_max_abs_diff=float((phi_torch - phi_native).abs().max().item()),
-                          h2_equal=bool(float(other.h2.item()) == h2_native),
-                          sqnorm_rel_diff=abs(float(other.sqnorm.item()) - sq_native) / max(sq_native, 1e-300))
-        del other
     return dict(comm=eng.comm, comm_note=comm_note, comm_crosscheck=crosscheck, n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
                 ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3, parity_relerr=relerr, parity_rows=nrows,
                 window=dict(timed_steps=stats1[0] - stats0[0], hits=stats1[1] - stats0[1]) if has_window else None)
 
 
-def cpu_baseline(wl, T64, G64, rows):
+def crosscheck_comms(torch, dist, wl, device, rank, world, group, steps=4):
+    """Several ranks: the same steps with torch.distributed issuing the collectives between the rank segments and with the
+    library's own RCCL communicator issuing them inside stein_rank_step -- same kernels, same data, so phi and the bandwidth
+    must come out bit-identical at every step (|phi|^2 to the order of its fp64 rank sum).  Also reads back, through
+    stein_comm_info, how many ranks the library's RCCL communicator really has."""
+    import ctypes
+    from stein_amd import _lib
+    from stein_amd.engine import SvgdEngine
+    from stein_amd.optimizers import AdagradGradientDescent
+    n, d = wl["n"], wl["d"]
+    nl = n // world
+    _, _, theta0, G = make_inputs(n, d, rank * nl, nl, device, torch)
+    res = {}
+    try:
+        native = SvgdEngine(n, d, device=device, group=group, comm="native")
+    except Exception as exc:      # collective: raised on every rank or on none
+        return {"native_available": False, "why": "%s: %s" % (type(exc).__name__, exc)}
+    nr, rk = ctypes.c_int(-1), ctypes.c_int(-1)
+    _lib.call("stein_comm_info", native._comm, ctypes.byref(nr), ctypes.byref(rk))
+    res.update(native_available=True, rccl_nranks=int(nr.value), rccl_rank=int(rk.value))
+    other = SvgdEngine(n, d, device=device, group=group, comm="torch")
+    th = {"native": theta0.clone(), "torch": theta0.clone()}
+    gd = {k: AdagradGradientDescent(learning_rate=1e-3, alpha=0.9) for k in th}
+    worst_phi, h2_equal, worst_sq, hits = 0.0, True, 0.0, []
+    for _ in range(steps):
+        pn = native.compute_phi(th["native"], G).clone()
+        pt = other.compute_phi(th["torch"], G).clone()
+        torch.cuda.synchronize(device)
+        worst_phi = max(worst_phi, float((pn - pt).abs().max().item()))
+        h2_equal = h2_equal and float(native.h2.item()) == float(other.h2.item())
+        sq = float(other.sqnorm.item())
+        worst_sq = max(worst_sq, abs(float(native.sqnorm.item()) - sq) / max(sq, 1e-300))
+        hits.append([native.window_hit, other.window_hit])
+        gd["native"].apply_(th["native"], pn, native.sqnorm)
+        gd["torch"].apply_(th["torch"], pt, other.sqnorm)
+    res.update(steps=steps, phi_max_abs_diff=worst_phi, h2_equal=h2_equal, sqnorm_rel_diff=worst_sq, window_hits=hits,
+               theta_equal=bool(torch.equal(th["native"], th["torch"])))
+    native.close()
+    return res
+
+
+def train_on_batch_entry(torch, device, steps, warmup):
+    """One GPU, C3 shape: SteinSampler.train_on_batch with the device score producer of the logistic-regression example
+    (stein_amd.scores.GlmScore: 255 weights + log alpha, minibatch 50 of 16000 points) -- the score is RECOMPUTED from theta
+    every iteration, so the median moves as it does in a real run and the window has to follow it."""
+    from stein_amd.optimizers import AdagradGradientDescent
+    from stein_amd.samplers import SteinSampler
+    from stein_amd.scores import GlmScore
+    n, nf, batch, ntrain = 16384, 255, 50, 16000
+    g = torch.Generator(device=device).manual_seed(7)
+    X = torch.randn(batch, nf, device=device, generator=g)
+    y = (torch.rand(batch, device=device, generator=g) < 0.5).float()
+    theta0 = 0.1 * torch.randn(n, nf + 1, device=device, generator=g)
+    s = SteinSampler(n, None, AdagradGradientDescent(learning_rate=1e-3, alpha=0.9), theta=theta0,
+                     score=GlmScore("logistic", nf, w_col=1, alpha_col=0, n_train=ntrain), device=device)
+    feed = {"X": X, "y": y}
+    for _ in range(warmup):
+        s.train_on_batch(feed)
+    torch.cuda.synchronize(device)
+    st0 = s.engine.window_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.train_on_batch(feed)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    st1 = s.engine.window_stats()
+    return {"what": "SteinSampler.train_on_batch at the C3 shape (n=16384, d=256): logistic-regression score recomputed from theta "
+                    "on the device every iteration (GlmScore, minibatch 50), fused SVGD step, Adagrad apply",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": n * steps / dt, "unit": "particle-updates/s",
+            "window": {"timed_steps": st1[0] - st0[0], "hits": st1[1] - st0[1]},
+            "finite": bool(torch.isfinite(s.theta_matrix).all().item())}
+
+
+def host_cores():
+    """(logical CPUs this process may run on, physical cores among them) -- from the affinity mask and /proc/cpuinfo"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    phys = set()
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in cpus:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in cpus:
+            phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except Exception:
+        phys = set()
+    return len(cpus), (len(phys) or None)
+
+
+def cpu_baseline(wl, T64, G64, rows, one_thread_rows=0):
+    """The NumPy oracle (the reference's dtype flow: fp32 kernel, fp64 contraction) timed on the host on a bounded row block
+    of the workload, with every BLAS thread the box gives and -- one_thread_rows > 0 -- once more on one thread
+    (SURVEY 8(d)); `cores` = the BLAS threads actually used, the physical core count is reported beside it."""
     from oracle import svgd_oracle as orc
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         info = threadpool_info()
-        cores = max([i.get("num_threads", 1) for i in info] or [1])
+        threads = max([i.get("num_threads", 1) for i in info] or [1])
         blas = ",".join(sorted({"%s %s" % (i.get("internal_api"), i.get("version")) for i in info}))
     except Exception:
-        cores, blas = os.cpu_count() or 1, "unknown"
+        threadpool_limits, threads, blas = None, os.cpu_count() or 1, "unknown"
+    logical, physical = host_cores()
     n, d = wl["n"], wl["d"]
     rows = min(rows, n)
     gd = orc.AdagradState(learning_rate=1e-3, alpha=0.9)
     t0 = time.perf_counter()
     orc.svgd_step_rows(T64, G64, 0, rows, gd, np.float32)
     dt = time.perf_counter() - t0
-    return dict(value=rows / dt, unit="particle-updates/s", cores=int(cores), kind="port",
-                sample="one step of the NumPy oracle (fp32 kernel, fp64 contraction, %s) on rows [0,%d) of the same "
-                       "n=%d d=%d inputs: %.1f s of CPU work; the reference's TF-1.12 graph cannot run here" %
-                       (blas, rows, n, d, dt),
-                seconds=dt)
+    out = dict(value=rows / dt, unit="particle-updates/s", cores=int(threads), kind="port",
+               blas_threads=int(threads), logical_cpus=logical, physical_cores=physical,
+               sample="one step of the NumPy oracle (fp32 kernel, fp64 contraction, %s) on rows [0,%d) of the same "
+                      "n=%d d=%d inputs: %.1f s of CPU work; the reference's TF-1.12 graph cannot run here" %
+                      (blas, rows, n, d, dt),
+               seconds=dt)
+    if one_thread_rows and threadpool_limits is not None:
+        r1 = min(one_thread_rows, n)
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            orc.svgd_step_rows(T64, G64, 0, r1, orc.AdagradState(learning_rate=1e-3, alpha=0.9), np.float32)
+            d1 = time.perf_counter() - t0
+        out["one_thread"] = dict(value=r1 / d1, unit="particle-updates/s", cores=1,
+                                 sample="the same on ONE thread, rows [0,%d): %.1f s" % (r1, d1), seconds=d1)
+    return out
+
+
+def cpu_extrapolations(base, n0, d0):
+    """C4 / C5 host numbers by the n^2 d law from a measured full step ('C4/C5 extrapolated by the n^2 d law and
+    labelled as such'): seconds per step scale with n^2 d, particle-updates/s with 1 / (n d)."""
+    out = {}
+    for key, (n, d) in (("c4", (8192, 2001)), ("c5", (131072, 256))):
+        f = (float(n) * n * d) / (float(n0) * n0 * d0)
+        ent = {"n": n, "d": d, "label": "EXTRAPOLATED from the measured n=%d d=%d step by the n^2 d law, not measured" % (n0, d0),
+               "seconds_per_step": base["seconds"] * f, "value": n / (base["seconds"] * f), "unit": "particle-updates/s",
+               "cores": base["cores"]}
+        if "one_thread" in base:
+            s1 = base["one_thread"]["seconds"] * (float(n0) / one_rows(base)) * f
+            ent["one_thread"] = {"seconds_per_step": s1, "value": n / s1, "cores": 1}
+        out[key] = ent
+    return out
+
+
+def one_rows(base):
+    """rows of the one-thread sample (parsed back from its own record)"""
+    return int(base["one_thread"]["sample"].split("rows [0,")[1].split(")")[0])
 
 
 def pmc_traffic(workload_key, x3):
@@ -262,12 +378,12 @@ def pmc_traffic(workload_key, x3):
     try:
         with open(p) as f:
             rec = json.load(f)
-        val = rec.get(workload_key, {}).get("k_phi_x3fs_hbm_bytes" if x3 else "k_phi_partial_hbm_bytes")
-        if val is None:
-            return None, None
-        return val, "profiles/pmc_traffic.json <- %s, measured at commit %s" % (rec.get("source", "?"), rec.get("commit", "?"))
+        ent = rec.get(workload_key, {})
+        val = ent.get("k_phi_x3fs_hbm_bytes" if x3 else "k_phi_partial_hbm_bytes")
+        src = "profiles/pmc_traffic.json <- %s, measured at commit %s" % (rec.get("source", "?"), rec.get("commit", "?"))
+        return val, (src if val is not None else None), (ent.get("k_phi_x3fs_mfma_busy_frac") if x3 else None), ent
     except Exception:
-        return None, None
+        return None, None, None, {}
 
 
 def main():
@@ -279,7 +395,12 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override the workload's particle count (experiments)")
     ap.add_argument("--d", type=int, default=0, help="override the workload's parameter count (experiments)")
     ap.add_argument("--cpu-rows", type=int, default=16384, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rows-one-thread", type=int, default=2048, help="rows of the one-thread CPU sample (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="several ranks: who issues the timed steps' collectives (torch.distributed over RCCL, or the "
+                         "library's own RCCL communicator); the other way is run once afterwards as a cross-check")
+    ap.add_argument("--no-train-on-batch", action="store_true", help="skip the SteinSampler.train_on_batch entry (one GPU)")
     ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
     ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief C1 / C2 / C4 timings (one GPU)")
@@ -320,7 +441,7 @@ def main():
         wl["n"], wl["d"] = args.n or wl["n"], args.d or wl["d"]
         wl["name"] = "custom n=%d d=%d fp32" % (wl["n"], wl["d"])
     env_x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
-    res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup)
+    res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm)
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
     value = n * args.steps / res["elapsed"]
@@ -328,14 +449,20 @@ def main():
     k_ms = res["stages"].get("contract")
     flops = 4.0 * nl * n * d
     alg = flops / (k_ms * 1e-3) if k_ms else None
-    traffic, traffic_src = pmc_traffic(args.workload, res["x3"]) if world == 1 else (None, None)
+    traffic, traffic_src, mfma_busy, pmc_ent = pmc_traffic(args.workload, res["x3"]) if world == 1 else (None, None, None, {})
     if res["x3"]:
         roof = {
             "kernel": "k_phi_x3fs (exp + split-precision MFMA K.[G|theta] contraction, %d 16-bit products per operand pair)" % nprod,
             "bound": "mfma", "achieved": nprod * alg / 1e12 if alg else None, "peak": PEAK_16BIT_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": nprod * alg / PEAK_16BIT_MFMA if alg else None,
-            "note": "achieved = EXECUTED 16-bit MFMA flops (%d products x the algorithmic 4 n_local n d) / mean kernel time, "
-                    "against the dense fp16/bf16 MFMA peak: the fraction of the pipe the kernel runs on" % nprod,
+            "frac_executed": nprod * alg / PEAK_16BIT_MFMA if alg else None,
+            "frac_algorithmic": alg / PEAK_16BIT_MFMA if alg else None,
+            "mfma_busy_frac": mfma_busy,
+            "note": "frac = frac_executed = EXECUTED 16-bit MFMA flops (%d products x the algorithmic 4 n_local n d) / mean kernel "
+                    "time / the dense fp16/bf16 MFMA peak: the fraction of the pipe the kernel runs on.  frac_algorithmic = the "
+                    "algorithmic 4 n_local n d flops alone against the same peak.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
+                    "(1024 SIMDs x 2.4 GHz x kernel time) from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), "
+                    "an independent reading of frac_executed" % nprod,
             "fp32_equivalent_tflops": alg / 1e12 if alg else None,
             "fp32_equivalent_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA if alg else None,
         }
@@ -377,12 +504,33 @@ def main():
         "parity_sample_relerr": res["parity_relerr"],
         "parity_sample_rows": res["parity_rows"],
     }
+    # the distance pass (north star: "achieved HBM GB/s on the distance pass"): one rank stores the 128 x 128 tiles on and
+    # above the diagonal, a row block all of its tiles; 2 n_local n d algorithmic flops (half with the symmetry), x nprod executed
+    d_ms = res["stages"].get("distance")
+    if d_ms and res["x3"]:
+        tiles = (n // 128) * (n // 128 + 1) // 2 if world == 1 else (nl // 128) * (n // 128)
+        stored = tiles * 128 * 128 * 4.0 if n % 128 == 0 and nl % 128 == 0 else None
+        dflop = 2.0 * nl * n * d * (0.5 if world == 1 else 1.0)
+        out["distance_pass"] = {
+            "kernel": "k_distance_panel (operand panel in LDS, strips streamed from L2)" if (nl // 128) * (n // 32) >= 16384 and d <= 256
+                      and n % 128 == 0 and nl % 128 == 0 else "k_distance_x3 (one 128 x 128 tile per workgroup)",
+            "ms_per_launch": d_ms, "bound": "hbm",
+            "stored_bytes": stored, "achieved_write_GBps": stored / (d_ms * 1e-3) / 1e9 if stored else None,
+            "peak_GBps": 8000.0, "frac_of_hbm_peak": stored / (d_ms * 1e-3) / 8e12 if stored else None,
+            "executed_mfma_tflops": nprod * dflop / (d_ms * 1e-3) / 1e12,
+            "frac_of_16bit_mfma_peak": nprod * dflop / (d_ms * 1e-3) / PEAK_16BIT_MFMA,
+            "hbm_bytes_measured": pmc_ent.get("k_distance_hbm_bytes") if world == 1 else None,
+            "note": "the pass writes D once (algorithmic bytes = stored bytes) and executes %d x n^2 d MFMA flops with the "
+                    "symmetry; both floors are ~0.085 ms at C3" % nprod}
     if world > 1:
         out["collectives"] = {"issued_by": {"native": "libsteinhip (own RCCL communicator, stein_rank_step: one C call per step)",
                                             "torch": "torch.distributed (backend %s) between the rank segments" % dist.get_backend(group)}[res["comm"]],
-                              "note": res["comm_note"], "crosscheck_vs_torch_collectives": res["comm_crosscheck"]}
+                              "note": res["comm_note"], "backend": str(dist.get_backend(group)),
+                              "torch_world_size": int(dist.get_world_size(group))}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, res["T64"], res["G64"], args.cpu_rows)
+        out["cpu_baseline"] = cpu_baseline(wl, res["T64"], res["G64"], args.cpu_rows, one_thread_rows=args.cpu_rows_one_thread)
+        if args.workload == "c3" and args.cpu_rows >= n:
+            out["cpu_baseline"]["extrapolated"] = cpu_extrapolations(out["cpu_baseline"], n, d)
     del res
 
     # one GPU: what the headline does not show -- a step whose window misses, and the strict fp32-input MFMA kernels
@@ -406,22 +554,37 @@ def main():
                             "parity_sample_relerr": rf["parity_relerr"]}
         del rf
 
+    if world == 1 and not args.no_variants and not wl.get("bf16") and env_x3:
+        torch.cuda.empty_cache()
+        rt = run_workload(torch, dist, wl, device, rank, world, group, 10, 3, tile_distance=True)
+        out["tile_distance_path"] = {"what": "the same step with the distance pass on the per-tile kernel (k_distance_x3, round 2's) "
+                                             "instead of the panel-resident one: same-box A/B",
+                                     "steps": 10, "ms_per_step": rt["elapsed"] / 10 * 1e3,
+                                     "stage_ms": {k: round(v, 4) for k, v in rt["stages"].items()}}
+        del rt
+    if world == 1 and args.workload == "c3" and not args.no_train_on_batch:
+        torch.cuda.empty_cache()
+        out["train_on_batch"] = train_on_batch_entry(torch, device, args.steps, max(args.warmup, 3))
+
     if args.secondary != "none" and args.secondary != args.workload:
         wl2 = WORKLOADS[args.secondary]
         need = (wl2["n"] // world) * wl2["n"] * 4 * 1.15 + 4 * wl2["n"] * wl2["d"] * 8
         free = torch.cuda.mem_get_info(device)[0]
         if need < free * 0.9:
             torch.cuda.empty_cache()
-            r2 = run_workload(torch, dist, wl2, device, rank, world, group, args.secondary_steps, 3)   # 3 warm-up steps: the median predictor needs two medians of history
+            r2 = run_workload(torch, dist, wl2, device, rank, world, group, args.secondary_steps, 3, comm=args.comm)   # 3 warm-up steps: the median predictor needs two medians of history
             k2 = r2["stages"].get("contract")
             f2 = 4.0 * r2["n_local"] * r2["n"] * r2["d"]
+            np2 = (1 if wl2.get("bf16") else 3) if r2["x3"] else 1     # 16-bit products per operand pair (1: the fp32-input MFMA kernel)
             out["secondary"] = {
                 "workload": wl2["name"], "n": r2["n"], "d": r2["d"], "steps": args.secondary_steps,
                 "ms_per_step": r2["elapsed"] / args.secondary_steps * 1e3,
                 "value": r2["n"] * args.secondary_steps / r2["elapsed"], "unit": "particle-updates/s",
                 "scaling": "strong (fixed n=%d)" % r2["n"],
-                "contract_executed_tflops": 3 * f2 / (k2 * 1e-3) / 1e12 if k2 else None,
-                "contract_frac_of_16bit_mfma_peak": 3 * f2 / (k2 * 1e-3) / PEAK_16BIT_MFMA if k2 else None,
+                "contract_products_per_pair": np2,
+                "contract_executed_tflops": np2 * f2 / (k2 * 1e-3) / 1e12 if k2 else None,
+                ("contract_frac_of_16bit_mfma_peak" if r2["x3"] else "contract_frac_of_fp32_mfma_peak"):
+                    np2 * f2 / (k2 * 1e-3) / (PEAK_16BIT_MFMA if r2["x3"] else PEAK_FP32_MFMA) if k2 else None,
                 "stage_ms": {k: round(v, 4) for k, v in r2["stages"].items()}, "finite": r2["finite"],
                 "window": r2["window"], "parity_sample_relerr": r2["parity_relerr"],
             }
@@ -460,8 +623,27 @@ def main():
         except OSError:
             commit = None
     out["commit"] = commit
+    if world > 1 and str(dist.get_backend(group)) == "nccl" and not os.environ.get("STEIN_NO_CROSSCHECK"):
+        # Last, and guarded: the library's own communicator has only ever run on one-rank groups before this machine.  If the
+        # native-vs-torch cross-check hangs (a mismatched collective has no timeout in RCCL), a watchdog prints the line that
+        # is already complete -- the timed numbers above do not depend on it -- and ends the process.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("STEIN_CROSSCHECK_TIMEOUT", "120"))):
+                out["collectives"]["crosscheck_native_vs_torch"] = {"timed_out": True}
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            out["collectives"]["crosscheck_native_vs_torch"] = crosscheck_comms(torch, dist, wl, device, rank, world, group)
+        except Exception as exc:   # noqa: BLE001 -- reported, never silent
+            out["collectives"]["crosscheck_native_vs_torch"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        done.set()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(group=group)
         dist.destroy_process_group()

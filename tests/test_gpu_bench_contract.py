@@ -33,4 +33,24 @@ def test_bench_line_has_the_contract_keys(cuda):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["value"] > 0
+    # round 3: the fraction is named three ways, the host baseline says how many threads / cores it ran on and is timed on
+    # one thread as well, the distance pass reports its HBM write rate
+    for key in ("frac_executed", "frac_algorithmic", "mfma_busy_frac"):
+        assert key in roof, key
+    assert roof["frac_executed"] == roof["frac"] and 0.0 < roof["frac_algorithmic"] <= roof["frac_executed"]
+    for key in ("blas_threads", "logical_cpus", "physical_cores", "one_thread"):
+        assert key in cpu, key
+    assert cpu["one_thread"]["cores"] == 1 and cpu["one_thread"]["value"] > 0 and cpu["cores"] == cpu["blas_threads"]
+    dp = b["distance_pass"]
+    assert dp["bound"] == "hbm" and dp["achieved_write_GBps"] > 0 and 0.0 < dp["frac_of_hbm_peak"] < 1.0
     assert b["finite"] is True and b["parity_sample_relerr"] < 4e-3                            # bf16 inputs: K rounded to bf16
+
+
+def test_train_on_batch_entry(cuda):
+    """the C3-shaped SteinSampler.train_on_batch entry of the bench line: score recomputed every step, window statistics"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    ent = bench.train_on_batch_entry(torch, cuda, steps=6, warmup=3)
+    assert ent["finite"] and ent["ms_per_step"] > 0 and ent["window"]["timed_steps"] == 6
+    assert 0 <= ent["window"]["hits"] <= 6
