@@ -45,9 +45,19 @@ out = {"workload": "c3 n=16384 d=256 fp32 inputs, split fp16 x 2 GEMM path, fuse
        "commit": commit, "kernels": summ}
 json.dump(out, open(os.path.join(dst, name + "_pmc_summary.json"), "w"), indent=1)
 tr = {"source": "profiles/%s_pmc_summary.json" % name, "commit": commit, "c3": {}}
+avg_ns = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) for r in rows}
 for k, cs in summ.items():
     if k.startswith("k_phi_x3fs") and "hbm_bytes_per_launch_corrected" in cs:
         tr["c3"]["k_phi_x3fs_hbm_bytes"] = cs["hbm_bytes_per_launch_corrected"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and k in avg_ns:   # busy cycles summed over the 1024 SIMDs / (1024 x 2.4 GHz x time)
+            tr["c3"]["k_phi_x3fs_mfma_busy_frac"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * 2.4 * avg_ns[k])
+            tr["c3"]["k_phi_x3fs_avg_ns_rocprofv3"] = avg_ns[k]
+    if k.startswith("k_distance") and "hbm_bytes_per_launch_corrected" in cs:
+        tr["c3"]["k_distance_hbm_bytes"] = cs["hbm_bytes_per_launch_corrected"]
+        tr["c3"]["k_distance_kernel"] = k
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and k in avg_ns:
+            tr["c3"]["k_distance_mfma_busy_frac"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * 2.4 * avg_ns[k])
+            tr["c3"]["k_distance_avg_ns_rocprofv3"] = avg_ns[k]
 old = json.load(open(os.path.join(dst, "pmc_traffic.json")))
 if "k_phi_partial_hbm_bytes" in old.get("c3", {}):
     tr["c3"]["k_phi_partial_hbm_bytes"] = old["c3"]["k_phi_partial_hbm_bytes"]

@@ -2,10 +2,14 @@
 // with s_memtime.  In the shipped library every macro here expands to nothing and no stamp executes; the stamp values
 // leave a diagnostic kernel only through g_dp_stamps, which nothing else reads.
 #pragma once
+#ifdef STEIN_ABLATE_DPANEL   // ---- stein_dpanel.hip (k_distance_panel) ----------------------------------------------
 // timing-only ablations of k_distance_panel (wrong results; -DSTEIN_DP_ABL_NOSTORE: the regular strips keep their values alive
 // but store nothing)
 #ifdef STEIN_DP_ABL_NOSTORE
 #define DP_STORE16(ptr, val) asm volatile("" :: "v"((val).x), "v"((val).y), "v"((val).z), "v"((val).w), "v"(ptr))
+#elif defined(STEIN_DP_SC1_STORE)   // (experiment: write-through stores for D)
+typedef float dp_f4w __attribute__((ext_vector_type(4)));
+#define DP_STORE16(ptr, val) do { const dp_f4w v_ = {(val).x, (val).y, (val).z, (val).w}; float* p_ = (ptr); asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p_), "v"(v_) : "memory"); } while (0)
 #elif defined(STEIN_DP_NT_STORE)   // (experiment: streaming stores for D)
 typedef float dp_f4v __attribute__((ext_vector_type(4)));
 #define DP_STORE16(ptr, val) __builtin_nontemporal_store(dp_f4v{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<dp_f4v*>(ptr))
@@ -90,3 +94,100 @@ extern "C" int stein_debug_dp_slow(unsigned long long* host_out) {
 #define DP_STRIP_END(g, s) do {} while (0)
 #define DP_SLOW_FLUSH(p, w, lane) do {} while (0)
 #endif
+
+#endif   // STEIN_ABLATE_DPANEL
+
+#ifdef STEIN_ABLATE_X3
+// ---- stein_x3.hip (k_distance_x3, k_phi_x3fs): per-phase cycle sums of one wave per role and workgroup --------------------
+#ifdef STEIN_STAMPS
+__device__ u64 g_stamps[8];
+#define STAMP(k)                                                                  \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    const u64 now_ = __builtin_amdgcn_s_memtime();                                \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                           \
+    st_acc[k] += now_ - st_last;                                                  \
+    st_last = now_;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } while (0)
+__device__ u64 g_wave[24];   // contraction, per wave of the workgroup: [2 w] cycles working, [2 w + 1] cycles at the stage barrier
+extern "C" int stein_debug_waves(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave), sizeof(u64) * 24) != hipSuccess) return -1;
+  if (reset) { u64 z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+__device__ u64 g_wg[3 * 1024];   // contraction, per workgroup: real-time ticks (100 MHz) at kernel entry, main-loop start, main-loop end
+extern "C" int stein_debug_wg(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg), sizeof(u64) * 3 * 1024) != hipSuccess) return -1;
+  if (reset) { static u64 z[3 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+__device__ u64 g_xcd[16];   // distance pass: [x] latest workgroup end on XCD x (blockIdx % 8), [8 + x] earliest end; 100 MHz ticks
+extern "C" int stein_debug_xcd(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xcd), sizeof(u64) * 16) != hipSuccess) return -1;
+  if (reset) { u64 z[16]; for (int i = 0; i < 16; ++i) z[i] = i < 8 ? 0ull : ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_xcd), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+__device__ u64 g_clock[2];   // sums over the sampled waves of (shader-clock ticks, 100 MHz real-time ticks) inside the contraction's main loop
+extern "C" int stein_debug_clock(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock), sizeof(u64) * 2) != hipSuccess) return -1;
+  if (reset) { u64 z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+extern "C" int stein_debug_stamps(u64* host_out, int reset) {
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(u64) * 8) != hipSuccess) return -1;
+  if (reset) { u64 z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define X3_STAMP_DECL \
+  u64 st_acc[6] = {0, 0, 0, 0, 0, 0}; \
+  u64 st_last = __builtin_amdgcn_s_memtime();
+#define X3_STAMP_FLUSH_DISTANCE \
+  STAMP(3); \
+  if (t == 0) { \
+  for (int k = 0; k < 4; ++k) atomicAdd(&g_stamps[k], st_acc[k]); \
+  atomicAdd(&g_stamps[7], 1ull); \
+  const u64 rt = __builtin_amdgcn_s_memrealtime(); \
+  __builtin_amdgcn_s_waitcnt(0xC07F); \
+  atomicMax(reinterpret_cast<unsigned long long*>(&g_xcd[blockIdx.x & 7]), (unsigned long long)rt); \
+  atomicMin(reinterpret_cast<unsigned long long*>(&g_xcd[8 + (blockIdx.x & 7)]), (unsigned long long)rt); \
+  }
+#define X3_STAMP_FLUSH_PRODUCER \
+  if (t == 0) { \
+  for (int k = 0; k < 3; ++k) atomicAdd(&g_stamps[k], st_acc[k]); \
+  atomicAdd(&g_stamps[7], 1ull); \
+  } \
+  if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[1] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[2]); }
+#define X3_STAMP_WG_ENTRY \
+  if (t == 256 && blockIdx.x < 1024) { g_wg[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#define X3_STAMP_DECL_CONSUMER \
+  u64 st_acc[6] = {0, 0, 0, 0, 0, 0}; \
+  u64 st_last = __builtin_amdgcn_s_memtime(); \
+  const u64 clk0 = st_last, rt0 = __builtin_amdgcn_s_memrealtime(); \
+  __builtin_amdgcn_s_waitcnt(0xC07F); \
+  if (t == 256 && blockIdx.x < 1024) g_wg[3 * blockIdx.x + 1] = rt0;
+#define X3_STAMP_FLUSH_CONSUMER \
+  if (t == 256) { \
+  const u64 clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime(); \
+  __builtin_amdgcn_s_waitcnt(0xC07F); \
+  atomicAdd(&g_clock[0], clk1 - clk0); \
+  atomicAdd(&g_clock[1], rt1 - rt0); \
+  if (blockIdx.x < 1024) g_wg[3 * blockIdx.x + 2] = rt1; \
+  } \
+  if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[3] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[4]); } \
+  if (t == 256) \
+  for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]); \
+  if (t == 512) { \
+  atomicAdd(&g_stamps[5], st_acc[3] + st_acc[4]); \
+  atomicAdd(&g_stamps[6], st_acc[0]); \
+  }
+#else
+#define STAMP(k) do {} while (0)
+#define X3_STAMP_DECL do {} while (0)
+#define X3_STAMP_FLUSH_DISTANCE do {} while (0)
+#define X3_STAMP_FLUSH_PRODUCER do {} while (0)
+#define X3_STAMP_WG_ENTRY do {} while (0)
+#define X3_STAMP_DECL_CONSUMER do {} while (0)
+#define X3_STAMP_FLUSH_CONSUMER do {} while (0)
+#endif
+#endif   // STEIN_ABLATE_X3

@@ -63,10 +63,7 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
 //   SYM: the super-blocks on or above the diagonal, row by row (row sm holds (sm, sm..S-1)); inside a diagonal
 //        super-block only tiles with tile_n >= tile_m exist
 //   else: all super-blocks, row by row
-#ifndef STEIN_DSB
-#define STEIN_DSB 8
-#endif
-constexpr int DSB = STEIN_DSB;
+constexpr int DSB = 8;
 __host__ __device__ __forceinline__ long distance_grid(bool sym, int tiles_m, int tiles_n) {
   const long sm = (tiles_m + DSB - 1) / DSB, sn = (tiles_n + DSB - 1) / DSB;
   return (sym ? sn * (sn + 1) / 2 : sm * sn) * (DSB * DSB);
@@ -239,13 +236,8 @@ __device__ __forceinline__ void distance_store_rows(const float* __restrict__ st
   for (int k = 0; k < 8; ++k) {
     const int sr = (t >> 5) + 8 * k;
     const int row = tile_m * BM + (sr >> 5) * 64 + p * 32 + (sr & 31);
-#ifndef STEIN_ABL_NOROWSTORE
     const float4 v4 = *reinterpret_cast<const float4*>(stage + sr * EPI_STAGE_LD + 4 * f4);
     store_d4(D + d_index(row, brow0 + 4 * f4, ntc), v4.x, v4.y, v4.z, v4.w);
-#else   // (ablation build, never shipped)
-    const float4 keep = *reinterpret_cast<const float4*>(stage + sr * EPI_STAGE_LD + 4 * f4);
-    asm volatile("" :: "v"(keep.x), "v"(keep.y), "v"(keep.z), "v"(keep.w), "v"(row));
-#endif
   }
 }
 
@@ -309,9 +301,6 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
             if (STAGED) stage[(wy * 32 + 8 * g + h4 + q) * EPI_STAGE_LD + wx * 64 + j * 32 + l31] = v[q];
             else D[d_index(lrow, col, ntc)] = v[q];
           }
-#ifdef STEIN_ABL_NOMIRROR   // (ablation build, never shipped: keeps the values alive without the mirrored store)
-          asm volatile("" :: "v"(v[q]));
-#endif
         }
         if (DIAG) {
           // mirror images: a group whose four rows all lie above the diagonal goes out as one 16-byte store (4
@@ -368,10 +357,8 @@ __device__ __forceinline__ void distance_epilogue_body(const f32x16 (&acc)[2][2]
         }
         // transposed copy: this lane's 4 rows are 4 consecutive columns of row `col` (lrow4 % 4 == 0: they stay inside
         // one 32-column tile, 16-byte aligned).  Entries past n land in padding, which no later stage reads.
-#ifndef STEIN_ABL_NOMIRROR
         if (MIRROR && STOREM && cok && (!PRED || lrow4 < n_local))
           store_d4(D + d_index(col, lrow4, ntc), v[0], v[1], v[2], v[3]);
-#endif
       }
     }
   }

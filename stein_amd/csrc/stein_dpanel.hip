@@ -28,7 +28,8 @@
 // (i, j) for i <= j and, for i < j, the same VALUE at (j, i) -- D is exactly symmetric whatever the product order was.
 #include "stein_x3.h"
 #include "stein_x3_dev.h"
-#include "stein_ablate.h"
+#define STEIN_ABLATE_DPANEL
+#include "stein_ablate.h"   // DP_STAMP* / DP_STORE16: hooks of the diagnostic builds (nothing in the shipped library)
 
 constexpr int DP_THREADS = 512;        // 8 waves: two per SIMD
 constexpr int DP_RING = 4;             // k tiles of the strip operand in flight per wave
@@ -38,7 +39,23 @@ constexpr int DP_QCAP = 124;           // window entries a wave buffers before i
 constexpr int DP_QBYTES = 1024;
 constexpr int DP_PANEL = 16 * XPLANE;  // 128 KB: NP * ntk <= 16 planes of [128 rows][32 k]
 constexpr int DP_LDS = DP_PANEL + 8 * DP_STAGE + 8 * DP_QBYTES;   // 157,696 of the 163,840 bytes
-constexpr int DP_SWITCH = 6;           // price of a panel switch in the balance, in strips
+
+// Who works on what.  A segment = one row tile's run of column strips = one operand panel.
+//   row block (not SYM): segment g = row tile g, strips [0, 4 tiles_n): all equally long.
+//   SYM: the rows of the triangle are folded into "virtual rows" of equal length: virtual row v = row v (strips [4 v, 4 N)),
+//        then row N - 1 - v (strips [4 (N - 1 - v), 4 N)): 4 N + 4 strips whatever v (the middle row of an odd N stands alone).
+//        Segment 2 v is the long part, 2 v + 1 the short one.
+// The (virtual) rows are dealt to the workgroups whole: with fewer rows than workgroups, G / rows workgroups ("members")
+// share a row and take its strips INTERLEAVED (member m: strips m, m + M, m + 2 M, ...); with more rows than workgroups a
+// workgroup takes rows p, p + G, ... one after the other.  Workgroups that share an XCD hold neighbouring rows (xcd_remap),
+// so at any time all of an XCD's workgroups -- members of one row and of its neighbours alike -- sweep the same few column
+// strips: one wave pulls a strip's operand into the XCD's L2 and up to 31 others find it there.  That matters more than
+// anything else about this kernel: it moves ~1 GB of operand fragments per launch at C3, and with every workgroup on a
+// contiguous QUARTER of its row (round 3's first form) half of that still came from beyond the L2 (rocprofv3: 0.53 GB of
+// fetches + 0.54 GB of D stores in 0.21 ms = the fabric's whole bandwidth, and the D stores of some XCDs then stalled for
+// 100-200 us at a time).  Inside a workgroup the strips are dealt to the waves one by one by a counter in LDS.
+// (Also tried and dropped, round 3: strips drawn from per-row counters in global memory by teams of four workgroups, with
+// work stealing once a team had run dry: 0.206-0.219 ms at C3 against 0.192-0.204 for contiguous pieces.)
 
 // Who works on what.  A segment = one row tile's run of column strips = one operand panel.
 //   row block (not SYM): segment g = row tile g, strips [0, 4 tiles_n): all equally long.
@@ -68,20 +85,6 @@ __device__ __forceinline__ void dp_segment(int g, int tiles_n, int& row, int& le
     len = 4 * tiles_n;
   }
 }
-template <bool SYM>
-__device__ __forceinline__ long dp_prefix(int g, int tiles_n) {   // price of all segments before segment g
-  if (!SYM) return (long)g * (4l * tiles_n + DP_SWITCH);
-  const int v = g >> 1;
-  return (long)v * (4l * tiles_n + 4 + 2 * DP_SWITCH) + ((g & 1) ? DP_SWITCH + 4l * (tiles_n - v) : 0l);
-}
-template <bool SYM>
-__device__ __forceinline__ long dp_total(int tiles_m, int tiles_n) {
-  const int ng = dp_segments<SYM>(tiles_m, tiles_n);
-  int row, len;
-  dp_segment<SYM>(ng - 1, tiles_n, row, len);
-  return dp_prefix<SYM>(ng - 1, tiles_n) + (len ? len + DP_SWITCH : 0);
-}
-
 __device__ __forceinline__ const void* dp_uniform(const void* p) {   // make a wave-uniform pointer provably so
   const unsigned long long v = (unsigned long long)p;
   return reinterpret_cast<const void*>(
@@ -195,17 +198,14 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
 
   // ---- this workgroup's share of the strip order -----------------------------------------------------------------------
   const int G = gridDim.x, p = xcd_remap(blockIdx.x, G);
-  const int nseg = dp_segments<SYM>(tiles_m, tiles_n);
-  const long C = dp_total<SYM>(tiles_m, tiles_n);
-  const long c0 = C * p / G, c1 = C * (p + 1) / G;
-  int g = 0;
-  {
-    int lo = 0, hi = nseg;   // largest g with prefix(g) <= c0
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (dp_prefix<SYM>(mid, tiles_n) <= c0) lo = mid; else hi = mid;
-    }
-    g = lo;
+  const int U = SYM ? (tiles_n + 1) / 2 : tiles_m;          // (virtual) rows
+  int unit, member, members, unit_step;
+  if (U >= G) { unit = p; member = 0; members = 1; unit_step = G; }
+  else {   // M or M + 1 members per row, the rows with M + 1 first
+    const int M = G / U, big = G - U * M;
+    if (p < big * (M + 1)) { unit = p / (M + 1); member = p % (M + 1); members = M + 1; }
+    else { const int q = p - big * (M + 1); unit = big + q / M; member = q % M; members = M; }
+    unit_step = U;                                           // (one row per workgroup)
   }
   u32* const dealer = reinterpret_cast<u32*>(smem + DP_LDS);   // the next strip of the piece nobody has taken yet
   // per-lane constants
@@ -218,14 +218,13 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   float ri[8];
   DP_STAMP_DECL;
 
-  for (; g < nseg && dp_prefix<SYM>(g, tiles_n) < c1; ++g) {
+  for (; unit < U; unit += unit_step)
+  for (int half = 0; half < (SYM ? 2 : 1); ++half) {
     int I, len;
-    dp_segment<SYM>(g, tiles_n, I, len);
-    const long base = dp_prefix<SYM>(g, tiles_n) + DP_SWITCH;
-    const long sb_l = c0 - base, se_l = c1 - base;
-    const int sb = sb_l > 0 ? (int)sb_l : 0, se = se_l < len ? (int)se_l : len;
+    dp_segment<SYM>(SYM ? 2 * unit + half : unit, tiles_n, I, len);
+    const int sb = 0, se = len > member ? (len - member + members - 1) / members : 0;   // this workgroup's strips: member + members k
     if (se <= sb) continue;
-    const int cfirst = SYM ? 4 * I : 0;            // first column strip of the row
+    const int cfirst = (SYM ? 4 * I : 0) + member; // column strip of the workgroup's strip k: cfirst + members k
     // ---- panel of row tile I -> LDS: wave w copies fragment w (1 KB) of every (k tile, plane) -------------------------
     __syncthreads();                               // everybody is done with the previous panel
     {
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
     int s = sb + w, s1 = sb + 8 + w;
     if (s < se) {
       auto strip_base = [&](int strip) {           // operand fragments of column strip `strip` (k tile 0, plane 0, block 0)
-        const long j0 = 32l * (cfirst + strip);
+        const long j0 = 32l * (cfirst + members * strip);
         return reinterpret_cast<const u16*>(dp_uniform(T3 + ((size_t)(j0 >> 7) * ntk * 3) * XTILE_E + ((j0 & 127) >> 4) * 512));
       };
       // The streamed memory operations are inline asm (neither counted nor waited for by the compiler, stein_x3_dev.h).  Each
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         }
       };
       auto request_norms = [&](int strip) {
-        const float* rb = reinterpret_cast<const float*>(dp_uniform(r + 32l * (cfirst + strip)));
+        const float* rb = reinterpret_cast<const float*>(dp_uniform(r + 32l * (cfirst + members * strip)));
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:64"
                      : "=&v"(rj[0]), "=&v"(rj[1]) : "v"(roff), "s"(rb) : "memory");
       };
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         DP_STAMP(2);
         stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
-        const int c32 = cfirst + s;
+        const int c32 = cfirst + members * s;
         float* __restrict__ dt = D + ((size_t)I * ntc + c32) * DT_ELEMS;
         const bool diag = SYM && (c32 >> 2) == I;
         const u32 wt = SYM ? 2u : 1u;

@@ -60,49 +60,8 @@
 constexpr int PEXP_H2 = 14;   // KIND 2: P = exp2(c D + 14), in (0, 2^14] (fp16 normal range down to P = 2^-28)
 template <int KIND> struct SplitTraits { static constexpr int pexp = KIND == 2 ? PEXP_H2 : 0; };
 
-#ifdef STEIN_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of one wave per role and workgroup
-__device__ u64 g_stamps[8];
-#define STAMP(k)                                                                  \
-  do {                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    const u64 now_ = __builtin_amdgcn_s_memtime();                                \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                           \
-    st_acc[k] += now_ - st_last;                                                  \
-    st_last = now_;                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-  } while (0)
-__device__ u64 g_wave[24];   // contraction, per wave of the workgroup: [2 w] cycles working, [2 w + 1] cycles at the stage barrier
-extern "C" int stein_debug_waves(u64* host_out, int reset) {
-  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave), sizeof(u64) * 24) != hipSuccess) return -1;
-  if (reset) { u64 z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-__device__ u64 g_wg[3 * 1024];   // contraction, per workgroup: real-time ticks (100 MHz) at kernel entry, main-loop start, main-loop end
-extern "C" int stein_debug_wg(u64* host_out, int reset) {
-  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg), sizeof(u64) * 3 * 1024) != hipSuccess) return -1;
-  if (reset) { static u64 z[3 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-__device__ u64 g_xcd[16];   // distance pass: [x] latest workgroup end on XCD x (blockIdx % 8), [8 + x] earliest end; 100 MHz ticks
-extern "C" int stein_debug_xcd(u64* host_out, int reset) {
-  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xcd), sizeof(u64) * 16) != hipSuccess) return -1;
-  if (reset) { u64 z[16]; for (int i = 0; i < 16; ++i) z[i] = i < 8 ? 0ull : ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_xcd), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-__device__ u64 g_clock[2];   // sums over the sampled waves of (shader-clock ticks, 100 MHz real-time ticks) inside the contraction's main loop
-extern "C" int stein_debug_clock(u64* host_out, int reset) {
-  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock), sizeof(u64) * 2) != hipSuccess) return -1;
-  if (reset) { u64 z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-extern "C" int stein_debug_stamps(u64* host_out, int reset) {
-  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(u64) * 8) != hipSuccess) return -1;
-  if (reset) { u64 z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-#else
-#define STAMP(k) do {} while (0)
-#endif
+#define STEIN_ABLATE_X3
+#include "stein_ablate.h"   // STAMP / X3_STAMP_*: phase-stamp hooks of the diagnostic builds (nothing in the shipped library)
 
 __device__ __forceinline__ int xswz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
 // LDS image of a P plane in the contraction: [128 rows][64 B], chunk c of row r at 16 * (c ^ g((r >> 2) & 3)) with
@@ -389,10 +348,6 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
   unsigned char* Bs = smem + OP;
   int tile_m, tile_n;
   if (!distance_tile<SYM>(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n)) return;
-#ifdef STEIN_STAGGER   // (experiment build: de-phase the workgroups that share a CU)
-  if (blockIdx.x < 768)
-    for (int i = 0; i < (int)(blockIdx.x / 256) * STEIN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wy = wid >> 1, wx = wid & 1;
   const long arow0 = row0 + (long)tile_m * BM, brow0 = (long)tile_n * BN;
@@ -414,10 +369,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
   // the next k tile's operands are prefetched into registers under the MFMAs (a second register set, two tiles
   // ahead, bought nothing and costs the third workgroup per CU)
   u32x4 ra[6], rb[6];
-#ifdef STEIN_STAMPS
-  u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
-  u64 st_last = __builtin_amdgcn_s_memtime();
-#endif
+  X3_STAMP_DECL;
   t3_load<NP>(pa0, pa1, 0, ra);
   t3_load<NP>(pb0, pb1, 0, rb);
   for (int kt = 0; kt < ntk; ++kt) {
@@ -426,58 +378,19 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_distance_x3(const u16* __restri
     STAMP(0);   // waiting for the tile's loads + LDS stores
     __syncthreads();
     STAMP(1);   // barrier
-#ifndef STEIN_ABL_NOLOAD   // (ablation builds: scratch/build_variant.py; never shipped)
     if (kt + 1 < ntk) {
       t3_load<NP>(pa0, pa1, kt + 1, ra);
       t3_load<NP>(pb0, pb1, kt + 1, rb);
     }
-#endif
-#ifndef STEIN_ABL_NOMFMA
     x3_mma_tile<NP>(As, Bs, wy, wx, lane, acc);
-#else
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(acc[i][j][e]));
-#endif
     STAMP(2);   // load issue + fragment reads + MFMAs
     __syncthreads();
     STAMP(1);
   }
-#ifndef STEIN_ABL_NOEPI
   // SYM: only the tiles on and above the diagonal are stored (the contraction reads the others transposed)
-#ifdef STEIN_NO_UPPER   // (A/B build: the full mirrored image)
-  distance_epilogue<SYM, SYM>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
-                              two_s_v, spec, spec_buf);
-#else
   distance_epilogue<SYM, false>(acc, reinterpret_cast<u32*>(smem), D, n, n_local, ldD, tile_m, tile_n, hist0, pf,
                                 two_s_v, spec, spec_buf);
-#endif
-#else
-  {
-    float sum = two_s_v + pf.norm;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
-    D[d_index(tile_m * BM + (t >> 1), tile_n * BN + (t & 1), ldD >> 5)] = sum;
-  }
-#endif
-#ifdef STEIN_STAMPS
-  STAMP(3);     // epilogue
-  if (t == 0) {
-    for (int k = 0; k < 4; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
-    atomicAdd(&g_stamps[7], 1ull);
-    const u64 rt = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    atomicMax(reinterpret_cast<unsigned long long*>(&g_xcd[blockIdx.x & 7]), (unsigned long long)rt);
-    atomicMin(reinterpret_cast<unsigned long long*>(&g_xcd[8 + (blockIdx.x & 7)]), (unsigned long long)rt);
-  }
-#endif
+  X3_STAMP_FLUSH_DISTANCE;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,11 +471,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
   // the partial last stage keeps its order.  (The order of the k tiles inside the fp32 accumulation changes with it --
   // deterministically.)
   const int nstage = (ntile + FS_KT - 1) / FS_KT;
-#ifdef STEIN_ROT   // (experiment builds)
-  const int rot = (cb * STEIN_ROT) % FS_KT;
-#else
   const int rot = (cb % FS_KT) * (cblocks >= FS_KT ? 1 : FS_KT / cblocks) % FS_KT;
-#endif
   auto tile_at = [&](int stage, int u) {     // u may run past the stage: u >= FS_KT continues in the next stage
     const int st2 = stage + u / FS_KT, u2 = u % FS_KT;
     return st2 * FS_KT + ((st2 + 1) * FS_KT <= ntile ? ((u2 + rot) & (FS_KT - 1)) : u2);
@@ -583,9 +492,6 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
   if (t < 256) {
     // ================================ PRODUCER ================================
     const int pt = t;
-#ifdef STEIN_ABL_P_PRIO
-    __builtin_amdgcn_s_setprio(STEIN_ABL_P_PRIO);
-#endif
     const int lr = pt >> 3, lc = (pt & 7) * 4;   // P staging: rows lr + 32p, 4 consecutive j
     float rs[PR];
 #pragma unroll
@@ -651,13 +557,11 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[p][e] = __builtin_fmaf(cexp, rd[p][e], pofs);
       __builtin_amdgcn_sched_barrier(0);
-#ifndef STEIN_ABL_P_NOEXP   // (ablation build: no transcendental)
 #pragma unroll
       for (int p = 0; p < PR; ++p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[p][e] = __builtin_amdgcn_exp2f(q[p][e]);
       __builtin_amdgcn_sched_barrier(0);
-#endif
       if (!full) {   // columns past jend hold whatever the padding holds: force P = 0 there
         const int j = j0 + lc;
 #pragma unroll
@@ -685,12 +589,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
 #pragma unroll
         for (int p = 0; p < PR; ++p) {
           unsigned char* dst = buf + (lr + 32 * p) * XROW + pswz(lr, lc >> 3) + (lc & 4) * 2;   // (lr+32p)>>2&3 == lr>>2&3
-#ifdef STEIN_ABL_P_NOLDSW   // (ablation build: the producers write nothing to LDS)
-          asm volatile("" :: "v"(hi[p][0]), "v"(hi[p][1]), "v"(lo[p][0]), "v"(lo[p][1]), "v"(dst));
-#else
           *reinterpret_cast<uint2*>(dst) = make_uint2(hi[p][0], hi[p][1]);
           *reinterpret_cast<uint2*>(dst + PLN) = make_uint2(lo[p][0], lo[p][1]);
-#endif
         }
       } else {
 #pragma unroll
@@ -758,10 +658,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       }
     };
     auto jt = [&](int tile) { return jbeg + tile * BK; };   // tile index -> first column (jbeg % 32 == 0)
-#ifdef STEIN_STAMPS
-    u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
-    u64 st_last = __builtin_amdgcn_s_memtime();
-#endif
+    X3_STAMP_DECL;
     // A pipeline stage holds FS_KT consecutive k tiles, so the workgroup synchronises once per FS_KT tiles.  Tile
     // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
 #pragma unroll
@@ -780,11 +677,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
           if (tr_now) produce_tr(buf + u * FS_KTB, rd[u % PD]);
           else produce(jt(tile_u), buf + u * FS_KTB, rd[u % PD]);
         }
-#if defined(STEIN_ABL_P_HALFLOAD)   // (ablation build: only the workgroups of column block 0 stream D)
-        if (cb == 0 && next_u < ntile) request(jt(next_u), tr_next, rd[u % PD]);
-#elif !defined(STEIN_ABL_P_NOLOAD)   // (ablation build: the producers re-use the first tiles' registers)
         if (next_u < ntile) request(jt(next_u), tr_next, rd[u % PD]);
-#endif
       }
     };
     produce_stage(0, smem);
@@ -797,17 +690,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       __syncthreads();
       STAMP(2);   // barrier
     }
-#ifdef STEIN_STAMPS
-#ifdef STEIN_ABL_P_HALFLOAD
-    if (t == 0 && cb == 0) {
-#else
-    if (t == 0) {
-#endif
-      for (int k = 0; k < 3; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
-      atomicAdd(&g_stamps[7], 1ull);
-    }
-    if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[1] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[2]); }
-#endif
+    X3_STAMP_FLUSH_PRODUCER;
     if (up) {
       // natural tiles: rows lr + 32 p, the 8 threads of a row are 8 consecutive lanes; mirrored tiles: rows 4 ig + e, the 8
       // threads of a row are the lanes jq = 0..7 (lane bits 3..5).  The two row sets meet in LDS (the stage buffers are
@@ -843,9 +726,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // than on 32x32x16 at the same cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7).
     const int ct = t - 256, lane = ct & 63, cw = ct >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-#ifdef STEIN_STAMPS
-    if (t == 256 && blockIdx.x < 1024) { g_wg[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-#endif
+    X3_STAMP_WG_ENTRY;
     // this wave's 128-column block of [G | theta] and its CJ 16-column blocks inside it
     const int g = RB == 8 ? 2 * cb + (cw >> 2) : 4 * cb + (cw >> 1);
     const int wcol = RB == 8 ? (cw & 3) * 32 : (cw & 1) * 64;   // first column inside the block (16 CJ columns)
@@ -888,13 +769,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // A fragments are read one 16-row block ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
     // all 24 reads (96 registers) to the top of the tile
     auto read_a = [&](const unsigned char* As, int i, u32x4 (&a)[3]) {
-#ifdef STEIN_ABL_C_NOLDS   // (ablation build: the matrix waves read no LDS)
-#pragma unroll
-      for (int s = 0; s < NP; ++s) { a[s] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(a[s])); }
-#else
 #pragma unroll
       for (int s = 0; s < NP; ++s) a[s] = *reinterpret_cast<const u32x4*>(As + aoff + i * 16 * XROW + s * PLN);
-#endif
     };
     auto mma_tile = [&](const unsigned char* As, const u32x4 (&b)[CJ][3]) {
       u32x4 a[2][3];
@@ -903,37 +779,19 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       for (int i = 0; i < RB; ++i) {
         if (i + 1 < RB) read_a(As, i + 1, a[(i + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef STEIN_ABL_C_NOMFMA   // (ablation build: the matrix waves read their operands and issue no MFMA)
-#pragma unroll
-        for (int s = 0; s < NP; ++s) asm volatile("" :: "v"(a[i & 1][s]), "v"(b[0][s]), "v"(b[1][s]));
-#else
 #pragma unroll
         for (int j = 0; j < CJ; ++j) acc[i][j] = x3_products16<NP>(a[i & 1], b[j], acc[i][j]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     if (ntile > 0) load_b(tile_at(0, 0), bX);
-#ifdef STEIN_ABL_C_NOVLOAD
-    if (ntile > 0) load_b(tile_at(0, 0), bY);
-#endif
     __syncthreads();
-#ifdef STEIN_STAMPS
-    u64 st_acc[6] = {0, 0, 0, 0, 0, 0};
-    u64 st_last = __builtin_amdgcn_s_memtime();
-    const u64 clk0 = st_last, rt0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (t == 256 && blockIdx.x < 1024) g_wg[3 * blockIdx.x + 1] = rt0;
-#endif
+    X3_STAMP_DECL_CONSUMER;
     for (int st = 0; st < nstage; ++st) {
       STAMP(5);
       const unsigned char* As = smem + (st & 1) * FS_STAGE;
       auto after = [&](int u) { return tile_at(st, u); };   // the tile in slot u of this stage (u >= FS_KT: of the next stage)
-#ifdef STEIN_ABL_C_NOVLOAD   // (ablation build: the matrix waves keep the first V fragments)
-      constexpr bool kLoadV = false;
-#else
       constexpr bool kLoadV = true;
-#endif
 #pragma unroll
       for (int u = 0; u < FS_KT; u += 2) {
         if (after(u) >= ntile) break;
@@ -945,9 +803,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
         // The two matrix waves of a SIMD (cw and cw + 4) take turns at the higher issue priority, tile by tile.  At equal
         // priority the older wave wins every arbitration: it ran ahead (1460 vs 2070 cycles per k tile, per-wave stamps)
         // and idled at the stage barrier while the younger one finished alone.  Measured -2 % on the launch.
-#ifndef STEIN_NO_PRIO_ALT   // (A/B builds)
         if (cw >> 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
-#endif
         mma_tile(As + u * FS_KTB, bX);
         if (n1) {
           const bool n2 = after(u + 2) < ntile;
@@ -955,9 +811,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
           STAMP(3);
           wait_b(kLoadV && n2, bY);
           STAMP(0);
-#ifndef STEIN_NO_PRIO_ALT
           if (cw >> 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#endif
           mma_tile(As + (u + 1) * FS_KTB, bY);
         }
       }
@@ -965,22 +819,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
       __syncthreads();
       STAMP(4);   // consumer: barrier
     }
-#ifdef STEIN_STAMPS
-    if (t == 256) {
-      const u64 clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      atomicAdd(&g_clock[0], clk1 - clk0);
-      atomicAdd(&g_clock[1], rt1 - rt0);
-      if (blockIdx.x < 1024) g_wg[3 * blockIdx.x + 2] = rt1;
-    }
-    if ((t & 63) == 0) { atomicAdd(&g_wave[2 * (t >> 6)], st_acc[0] + st_acc[3] + st_acc[5]); atomicAdd(&g_wave[2 * (t >> 6) + 1], st_acc[4]); }
-    if (t == 256)
-      for (int k = 3; k < 5; ++k) atomicAdd(&g_stamps[k], st_acc[k]);
-    if (t == 512) {   // the second matrix wave of the same SIMD
-      atomicAdd(&g_stamps[5], st_acc[3] + st_acc[4]);
-      atomicAdd(&g_stamps[6], st_acc[0]);   // time spent waiting for the B fragments at the top of a tile
-    }
-#endif
+    X3_STAMP_FLUSH_CONSUMER;
     if (up) __syncthreads();   // the producers' row-sum exchange (same barrier count in both roles)
     if (g >= 2 * gblocks) return;   // (an odd block count leaves the last workgroup's upper waves without columns)
     float* __restrict__ Oz = (g < gblocks ? OG : OT) + (size_t)z * n_local * d;

@@ -1083,11 +1083,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
   if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW | STEIN_FLAG_TILE_DISTANCE)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
-#ifdef STEIN_LD_PAD   // (experiment builds: extra column tiles per row block of the distance image)
-  L->ld_dist = (int64_t)align_up((size_t)n, 64) + STEIN_LD_PAD;
-#else
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
-#endif
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
   // workgroups per unit of split and resident workgroups per round: the fp32 kernel tiles [G | theta] in 128-column
@@ -1096,11 +1092,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   // the split kernel's 64-row x 512-column form (k_phi_x3fs<NP, 4>: P built once per 512 columns, every D tile read by one
   // workgroup; needs an even number of 128-column blocks per matrix; same workgroup count and partial layout).  Measured
   // equal to the 128 x 256 form within +-1 % at C3 and C4 (scratch/README.md), so the shipped library keeps one form.
-#ifdef STEIN_PHI_WIDE   // (A/B builds)
-  L->phi_wide = (x3 && L->cblocks % 2 == 0) ? 1 : 0;
-#else
   L->phi_wide = 0;
-#endif
   const int64_t base = x3 ? L->tiles_m * L->cblocks : L->tiles_m * 2 * L->cblocks;
   const int64_t jt = (n + BK - 1) / BK;  // j tiles
   // k_phi_partial runs 3 workgroups per CU (156 registers): 768 resident blocks.  Every block does the same
@@ -1708,11 +1700,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
                              true, lv == STEIN_HIST_LEVELS - 1 ? fin : HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f})))
       return rc;
   // the split path's symmetric distance pass stores only the tiles on and above the diagonal
-#ifdef STEIN_NO_UPPER   // (A/B build: the full mirrored image of round 1)
-  const int df = STEIN_STAGE_SYMMETRIC;
-#else
   const int df = planes ? (STEIN_STAGE_SYMMETRIC | STEIN_STAGE_UPPER) : STEIN_STAGE_SYMMETRIC;
-#endif
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, df, stream))) return rc;
   STEIN_TSTAMP(STEIN_T_CONTRACT);
   if ((rc = stein_contract_partial(D, L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_out, planes,
