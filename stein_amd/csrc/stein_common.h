@@ -131,12 +131,14 @@ struct SpecState {
 static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
 // Third 64-byte block of the SELECT section (fused call only): "last workgroup out" tickets that let a kernel's last
 // workgroup do what used to be a one-workgroup follow-up launch (scales after the column maxima, the final resolve after
-// the level-2 histogram).  Zeroed by the fused call's first kernel; each ticket also resets itself.  (The |phi|^2 sum
-// after k_phi_finish's partials was tried the same way: its 1024 workgroups waiting on their stores cost more than the
-// launch saved.)
+// the level-2 histogram, the |phi|^2 sum after k_phi_finish's partials when that kernel has at most 512 workgroups -- with
+// 1024 of them waiting on their stores the ticket cost more than the launch it saved).  Zeroed by the fused call's first
+// kernel; each ticket also resets itself.
 struct FuseState {
-  u32 done_colmax, done_hist;
-  u32 pad[14];
+  u32 done_colmax, done_hist, done_finish;
+  u32 bar[2];      // k_hist_all: arrivals at its level barriers; the generation whose state has been published
+  u32 pub[7];      // k_hist_all: the select state the last arrival resolved (prefix[2], rank[2] as halves, diverged)
+  u32 pad[4];
 };
 static_assert(sizeof(FuseState) == 64, "FuseState must stay 64 bytes");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;

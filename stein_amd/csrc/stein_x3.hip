@@ -864,7 +864,7 @@ static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score,
 // fuse_done != NULL (fused call): the caller has zeroed the column maxima and the ticket, both matrices are given, and
 // the column-maxima kernel's last workgroup writes the scales itself
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
-                   const SteinLayout& L, char* planes, hipStream_t stream, u32* fuse_done) {
+                   const SteinLayout& L, char* planes, hipStream_t stream, u32* fuse_done, bool scales_written) {
   u16* T3 = reinterpret_cast<u16*>(planes + L.x3_t3);
   u16* Tt3 = reinterpret_cast<u16*>(planes + L.x3_tt3);
   u16* Gt3 = reinterpret_cast<u16*>(planes + L.x3_gt3);
@@ -887,7 +887,7 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
                        (int)n, (int)d, cmax, dc, zbase, sc, PEXP_H2, fuse_done);
     LAUNCH_CHECK("k_colmax");
   }
-  if (kind != 2 || !fuse_done) {
+  if ((kind != 2 && !scales_written) || (kind == 2 && !fuse_done)) {
     hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(256), 0, stream, cmax, dc, sc, kind == 2 ? PEXP_H2 : 0,
                        kind == 2 ? 1 : 0);
     LAUNCH_CHECK("k_make_scales");

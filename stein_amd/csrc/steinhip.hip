@@ -199,7 +199,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
 // speculative window hit: every launch is a few microseconds even when it returns at once).
 // Block-wide (256 threads): the select state after `levels` resolved levels, computed from the INITIAL state in
 // *st (ranks set by k_median_init, prefixes 0 -- nothing writes *st until resolve_all_body) and the global histograms.
+// FRESH: the histograms may hold atomics of THIS launch (the last workgroup out, the barrier of k_hist_all): device-scope
+// loads.  Otherwise earlier launches wrote them and plain loads do (served by the L2: a few thousand workgroups reading
+// the same 16 KB with device-scope loads queued on the handful of memory channels that hold it, ~50 us per pass at C2).
 struct ChainState { u32 prefix[2]; u64 rank[2]; bool two; };
+template <bool FRESH>
 __device__ __forceinline__ ChainState chain_resolve(const u64* hist_all, int levels, const SelState* st) {
   __shared__ u64 c_part[256];
   __shared__ u32 c_bin[2];
@@ -216,7 +220,7 @@ __device__ __forceinline__ ChainState chain_resolve(const u64* hist_all, int lev
       const u64* src = hl + ((cs.two && tg == 1) ? STEIN_HIST_BINS : 0);
       u64 mine[8], sum = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { mine[k] = load_fresh(src + t * 8 + k); sum += mine[k]; }   // may follow this kernel's own atomics
+      for (int k = 0; k < 8; ++k) { mine[k] = FRESH ? load_fresh(src + t * 8 + k) : src[t * 8 + k]; sum += mine[k]; }
       c_part[t] = sum;
       __syncthreads();
       for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
@@ -261,29 +265,15 @@ struct HistFinal {
 };
 __device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out);   // below
 
-template <int LEVEL, bool SYM, bool CHAIN = false>
-__global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
-                                              const SelState* st, u64* hist, const u32* __restrict__ skip,
-                                              HistFinal fin) {
-  if (skip && *skip) return;   // the speculative window already produced this step's median
-  u64* const hist_all = hist;
-  __shared__ u32 h[2 * STEIN_HIST_BINS];
-  for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
-  __syncthreads();
-
-  u32 pa, pb;
-  bool two;
-  if (CHAIN) {
-    const ChainState cs = chain_resolve(hist, LEVEL, st);
-    pa = cs.prefix[0]; pb = cs.prefix[1]; two = cs.two;
-    hist += (size_t)LEVEL * 2 * STEIN_HIST_BINS;
-  } else {
-    pa = st->prefix[0]; pb = st->prefix[1];
-    two = st->diverged != 0u;
-  }
+// one histogram pass of a workgroup over its share of the block (units blockIdx.x, blockIdx.x + gridDim.x, ...): digits of
+// LEVEL into the LDS histogram h[2][STEIN_HIST_BINS] (zeroed by the caller), given the prefixes the earlier levels fixed
+template <int LEVEL, bool SYM>
+__device__ __forceinline__ void hist_pass_body(const float* __restrict__ D, long ldD, int n_local, int n, u32* h, u32 pa, u32 pb,
+                                               bool two) {
   const int lane = threadIdx.x & 63;
   // one unit = one [128][32] tile of the tile-major block (16 KB, 4 x 16 B per thread); SYM skips the tiles that lie
-  // entirely below the diagonal
+  // entirely below the diagonal.  (Keeping the loads of two more units in flight -- three register sets in rotation --
+  // changed nothing at C2 or C3: the pass is not bound by the latency of its loads.)
   const long ntc = ldD >> 5;
   const int ntr = (n_local + DT_ROWS - 1) / DT_ROWS, ncol_tiles = (n + DT_COLS - 1) / DT_COLS;
   const long units = (long)ntr * ncol_tiles;
@@ -321,12 +311,99 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
       }
     }
   }
+}
+
+template <int LEVEL, bool SYM, bool CHAIN = false>
+__global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
+                                              const SelState* st, u64* hist, const u32* __restrict__ skip,
+                                              HistFinal fin) {
+  if (skip && *skip) return;   // the speculative window already produced this step's median
+  u64* const hist_all = hist;
+  __shared__ u32 h[2 * STEIN_HIST_BINS];
+  for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
+  __syncthreads();
+
+  u32 pa, pb;
+  bool two;
+  if (CHAIN) {
+    const ChainState cs = chain_resolve<false>(hist, LEVEL, st);
+    pa = cs.prefix[0]; pb = cs.prefix[1]; two = cs.two;
+    hist += (size_t)LEVEL * 2 * STEIN_HIST_BINS;
+  } else {
+    pa = st->prefix[0]; pb = st->prefix[1];
+    two = st->diverged != 0u;
+  }
+  hist_pass_body<LEVEL, SYM>(D, ldD, n_local, n, h, pa, pb, two);
   __syncthreads();
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
     if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
   if (CHAIN && LEVEL == STEIN_HIST_LEVELS - 1) {
     if (fin.done && last_workgroup_out(fin.done, gridDim.x)) resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
   }
+}
+
+// The whole chained radix select of the fused symmetric call in ONE launch, for blocks small enough that the launches
+// themselves were the cost (n <= HIST_ALL_MAX_N: when the window hit -- the usual case -- three launches returned at once,
+// a few microseconds each).  Here the workgroups of the one launch (all resident: the host keeps the grid to 2 per CU) meet
+// at a barrier behind each level: an arrival counter, and the LAST workgroup to arrive resolves the level once for
+// everybody (chain_resolve with device-scope loads: the other workgroups' histogram atomics were acknowledged before they
+// drew their ticket), publishes the select state in FuseState::pub and opens the gate.  The spin is bounded: on a machine
+// where the grid is not resident the launch returns (with a wrong median) instead of hanging.
+constexpr int HIST_ALL_MAX_N = 4096;
+constexpr int HIST_BLOCKS = 2048;      // workgroups of a histogram pass (C3, every step a miss: 0.61 ms of select with 2048, 0.77 with 1024, 1.17 with 512)
+constexpr int HIST_ALL_BLOCKS = 512;   // .. of k_hist_all, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
+__device__ __forceinline__ ChainState hist_level_barrier(FuseState* fs, u32 nblk, u32 generation, const u64* hist_all, int levels,
+                                                        const SelState* st) {
+  __shared__ u32 s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&fs->bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation * nblk - 1u ? 1u : 0u;
+  __syncthreads();
+  ChainState cs;
+  if (s_last) {
+    cs = chain_resolve<true>(hist_all, levels, st);
+    if (threadIdx.x == 0) {
+      const u32 w[7] = {cs.prefix[0], cs.prefix[1], (u32)cs.rank[0], (u32)(cs.rank[0] >> 32), (u32)cs.rank[1], (u32)(cs.rank[1] >> 32),
+                        cs.two ? 1u : 0u};
+#pragma unroll
+      for (int k = 0; k < 7; ++k) __hip_atomic_store(&fs->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&fs->bar[1], generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return cs;
+  }
+  if (threadIdx.x == 0)
+    for (int spin = 0; spin < (1 << 20) && load_fresh(&fs->bar[1]) < generation; ++spin) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  u32 w[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) w[k] = load_fresh(&fs->pub[k]);
+  cs.prefix[0] = w[0]; cs.prefix[1] = w[1];
+  cs.rank[0] = (u64)w[2] | ((u64)w[3] << 32); cs.rank[1] = (u64)w[4] | ((u64)w[5] << 32);
+  cs.two = w[6] != 0u;
+  return cs;
+}
+__global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, long ldD, int n, const SelState* st, u64* hist_all,
+                                                  const u32* __restrict__ hit, const u32* __restrict__ skip_l0, HistFinal fin,
+                                                  FuseState* fs /* bar[], pub[] zero at launch */) {
+  if (*hit) return;   // the speculative window already produced this step's median
+  __shared__ u32 h[2 * STEIN_HIST_BINS];
+  const int first = *skip_l0 == 0u ? 0 : 1;   // level 0 may have been taken by the distance kernel (an earlier launch)
+  ChainState cs = chain_resolve<false>(hist_all, first, st);
+  for (int level = first; level < STEIN_HIST_LEVELS; ++level) {
+    for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
+    __syncthreads();
+    if (level == 0) hist_pass_body<0, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two);
+    else if (level == 1) hist_pass_body<1, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two);
+    else hist_pass_body<2, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two);
+    __syncthreads();
+    u64* hl = hist_all + (size_t)level * 2 * STEIN_HIST_BINS;
+    for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
+      if (h[b]) atomicAdd(&hl[b], (u64)h[b]);
+    if (level + 1 < STEIN_HIST_LEVELS) cs = hist_level_barrier(fs, gridDim.x, (u32)(level - first + 1), hist_all, level + 1, st);
+  }
+  if (fin.done && last_workgroup_out(fin.done, gridDim.x)) resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
 }
 
 // one wave; hist points at this level's [2][STEIN_HIST_BINS] counters (already summed over ranks)
@@ -425,10 +502,15 @@ template <typename TIN>
 __global__ __launch_bounds__(256) void k_prologue(const TIN* __restrict__ T, int n, int d, float* __restrict__ r,
                                                   int row_blocks, SelState* st, SpecState* sp, FuseState* fs, u64 total,
                                                   u64* __restrict__ hist, u64* __restrict__ slots,
-                                                  u32* __restrict__ cmax, int ncmax, int allow_window) {
+                                                  u32* __restrict__ cmax, int ncmax, int allow_window,
+                                                  float* __restrict__ neutral_sc, int dc) {
   if ((int)blockIdx.x >= row_blocks) {
     const int gt = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x, gn = PRO_INIT_BLOCKS * 256;
     for (int i = gt; i < ncmax; i += gn) cmax[i] = 0u;
+    if (neutral_sc) {   // bf16 inputs: every operand scale is 1 (what k_make_scales(enable = 0) writes), no launch for it
+      for (int i = gt; i < 4 * dc; i += gn) neutral_sc[i] = 1.f;
+      if (gt == 0) { neutral_sc[4 * dc] = 1.f; neutral_sc[4 * dc + 1] = 2.f; neutral_sc[4 * dc + 2] = 1.f; }
+    }
     if (gt < 16) reinterpret_cast<u32*>(fs)[gt] = 0u;
     median_init_body(gt, gn, st, sp, total, hist, slots, allow_window);
     return;
@@ -747,7 +829,7 @@ __global__ void k_spec_update(const SelState* st, SpecState* sp) {
 // end of the chained radix select (fused call): all three resolves, the median / bandwidth, the predictor update;
 // one workgroup of 256 threads
 __device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out) {
-  const ChainState cs = chain_resolve(hist_all, STEIN_HIST_LEVELS, st);
+  const ChainState cs = chain_resolve<true>(hist_all, STEIN_HIST_LEVELS, st);
   if (threadIdx.x == 0) {
     st->prefix[0] = cs.prefix[0]; st->prefix[1] = cs.prefix[1];
     st->rank[0] = cs.rank[0]; st->rank[1] = cs.rank[1];
@@ -912,7 +994,10 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
                                                     const float* __restrict__ RS, const TIN* __restrict__ T,
                                                     const float* __restrict__ h2p, float* __restrict__ phi,
                                                     float* __restrict__ dK, double* __restrict__ sqpart, int n, int d,
-                                                    int row0, int n_local, int split, int vec) {
+                                                    int row0, int n_local, int split, int vec, u32* done,
+                                                    double* __restrict__ sq_out) {
+  // done != NULL (fused call, small grids): the last workgroup out also sums the partials -- in the order k_sum_partials
+  // uses, so the result is the same to the last bit -- which saves that launch
   __shared__ double red[4];
   const float h2 = *h2p;
   const float fn = (float)n;
@@ -929,7 +1014,8 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
       const long e = q << 2;
       float4 og = make_float4(0.f, 0.f, 0.f, 0.f), ot = og;
       float rs = 0.f;
-      for (int z = 0; z < split; ++z) {
+#pragma unroll 8
+      for (int z = 0; z < split; ++z) {   // unrolled: the loads of eight slices in flight, the sums in the same order
         const float4 a = *reinterpret_cast<const float4*>(OG + z * zs + e), b = *reinterpret_cast<const float4*>(OT + z * zs + e);
         og.x += a.x; og.y += a.y; og.z += a.z; og.w += a.w;
         ot.x += b.x; ot.y += b.y; ot.z += b.z; ot.w += b.w;
@@ -964,7 +1050,23 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
   __syncthreads();
-  if (threadIdx.x == 0) sqpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  const double part = (red[0] + red[1]) + (red[2] + red[3]);
+  if (!done) {
+    if (threadIdx.x == 0) sqpart[blockIdx.x] = part;
+    return;
+  }
+  // the partials cross workgroups: written with device-scope atomics, read with load_fresh (last_workgroup_out)
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<u64*>(sqpart) + blockIdx.x, (u64)__double_as_longlong(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!last_workgroup_out(done, gridDim.x)) return;
+  double s2 = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) s2 += __longlong_as_double((long long)load_fresh(reinterpret_cast<const u64*>(sqpart) + i));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) *sq_out = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, int count, double* out) {
@@ -1289,7 +1391,7 @@ static int hist_pass_impl(const float* dist, int64_t ld_dist, int64_t n_local, i
   if (sym && n_local != n) return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs a square block");
   if (chain && !sym) return fail(STEIN_E_BADARG, "the chained select is the fused symmetric call's");
   const long units = ((n_local + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);   // [128][32] tiles
-  const int blocks = (int)(units < 2048 ? units : 2048);
+  const int blocks = (int)(units < HIST_BLOCKS ? units : HIST_BLOCKS);
   u64* h = (u64*)hist + (chain ? 0 : (size_t)level * 2 * STEIN_HIST_BINS);
   const SelState* st = (const SelState*)select_state;
   hipStream_t s = (hipStream_t)stream;
@@ -1429,9 +1531,9 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
   return STEIN_OK;
 }
 
-extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
-                                     int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
-                                     float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
+static int contract_finish_impl(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
+                                int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
+                                float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream, u32* fuse_done) {
   if (!theta_all || !h2_dev || !phi_local || !sqnorm_out || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
@@ -1448,18 +1550,28 @@ extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
   const int vec = (d % 4 == 0) && al16(OG) && al16(OT) && al16(phi_local) && al16(dK_out) &&
                   al16((const float*)theta_all + (size_t)row0 * d);
+  if (L.sq_blocks > 512) fuse_done = nullptr;   // a ticket per workgroup: beyond a few hundred the separate launch is cheaper
   if (dtype == STEIN_BF16)
     hipLaunchKernelGGL(k_phi_finish<unsigned short>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
                        (const unsigned short*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0,
-                       (int)n_local, (int)L.split, 0);
+                       (int)n_local, (int)L.split, 0, fuse_done, sqnorm_out);
   else
     hipLaunchKernelGGL(k_phi_finish<float>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
                        (const float*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local,
-                       (int)L.split, vec);
+                       (int)L.split, vec, fuse_done, sqnorm_out);
   LAUNCH_CHECK("k_phi_finish");
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, SQ, (int)L.sq_blocks, sqnorm_out);
-  LAUNCH_CHECK("k_sum_partials");
+  if (!fuse_done) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, SQ, (int)L.sq_blocks, sqnorm_out);
+    LAUNCH_CHECK("k_sum_partials");
+  }
   return STEIN_OK;
+}
+
+extern "C" int stein_contract_finish(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
+                                     int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
+                                     float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream) {
+  return contract_finish_impl(theta_all, n, d, row0, n_local, dtype, h2_dev, phi_local, sqnorm_out, dK_out, workspace,
+                              ws_bytes, flags, stream, nullptr);
 }
 
 extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const void* theta_all, const void* score_all,
@@ -1672,13 +1784,15 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     if (dtype == STEIN_BF16)
       hipLaunchKernelGGL(k_prologue<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)theta_all, (int)n,
                          (int)d, r, row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax,
-                         allow_window);
+                         allow_window, planes ? (float*)((char*)planes + L.x3_sc) : (float*)nullptr, (int)L.x3_dc);
     else
       hipLaunchKernelGGL(k_prologue<float>, grid, dim3(256), 0, s, (const float*)theta_all, (int)n, (int)d, r,
-                         row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax, allow_window);
+                         row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax, allow_window,
+                         (float*)nullptr, 0);
     LAUNCH_CHECK("k_prologue");
   }
-  if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax)))
+  if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax,
+                                     dtype == STEIN_BF16 /* the prologue has written the neutral scales */)))
     return rc;
   STEIN_TSTAMP(STEIN_T_DISTANCE);
   if ((rc = distance_block_impl(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream, spec,
@@ -1695,6 +1809,13 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   // chained radix select: three passes that resolve the earlier levels themselves; the last workgroup of the third
   // resolves the rest.  Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
   const HistFinal fin{(SelState*)sel, spec, h2_out, &fuse->done_hist, (float)log((double)n)};
+  if (!solo && n <= HIST_ALL_MAX_N) {   // one launch for all three levels (in-launch barriers; at most 4 workgroups per CU)
+    const long units = ((n + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);
+    const int blocks = (int)(units < HIST_ALL_BLOCKS ? units : HIST_ALL_BLOCKS);
+    hipLaunchKernelGGL(k_hist_all, dim3(blocks), dim3(256), 0, s, (const float*)D, (long)L.ld_dist, (int)n,
+                       (const SelState*)sel, (u64*)hist, (const u32*)&spec->hit, (const u32*)&spec->skip_l0, fin, fuse);
+    LAUNCH_CHECK("k_hist_all");
+  } else
   for (int lv = 0; lv < (solo ? 0 : STEIN_HIST_LEVELS); ++lv)
     if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit,
                              true, lv == STEIN_HIST_LEVELS - 1 ? fin : HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f})))
@@ -1707,8 +1828,8 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
                                    workspace, ws_bytes, df, stream)))
     return rc;
   STEIN_TSTAMP(STEIN_T_FINISH);
-  if ((rc = stein_contract_finish(theta_all, n, d, row0, n_local, dtype, h2_out, phi_local, sqnorm_out, dK_out, workspace,
-                                  ws_bytes, planes ? STEIN_FLAG_X3 : 0, stream)))
+  if ((rc = contract_finish_impl(theta_all, n, d, row0, n_local, dtype, h2_out, phi_local, sqnorm_out, dK_out, workspace,
+                                ws_bytes, planes ? STEIN_FLAG_X3 : 0, stream, &fuse->done_finish)))
     return rc;
   STEIN_TSTAMP(STEIN_T_NSTAGES);
 #undef STEIN_TSTAMP
