@@ -1,4 +1,4 @@
-"""CPU, gloo, world_size 2: the multi-rank protocol of stein_amd.engine.SvgdEngine.
+"""CPU, gloo, world_size 2 (and once 8): the multi-rank protocol of stein_amd.engine.SvgdEngine.
 
 The HIP stages cannot run without a GPU, so the engine is given the NumPy stage model
 (oracle/staged_model.py, test infrastructure).  What is under test is the PRODUCT host logic: row
@@ -52,9 +52,8 @@ def _worker(rank, world, port, n, d, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,d", [(64, 6), (130, 9)])
-def test_two_rank_protocol_matches_single_rank(tmp_path, n, d):
-    world = 2
+@pytest.mark.parametrize("world,n,d", [(2, 64, 6), (2, 130, 9), (8, 1024, 5)])
+def test_sharded_protocol_matches_single_rank(tmp_path, world, n, d):
     mp.spawn(_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
     from oracle import svgd_oracle as orc
     rng = np.random.default_rng(42)
@@ -64,9 +63,8 @@ def test_two_rank_protocol_matches_single_rank(tmp_path, n, d):
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert all(bool(p["gathered_ok"]) for p in parts)
     # identical bandwidth / median / global norm on every rank
-    assert parts[0]["h2"][0] == parts[1]["h2"][0] == ref["h2"]
-    assert parts[0]["median"][0] == parts[1]["median"][0] == ref["median"]
-    assert parts[0]["sqnorm"][0] == parts[1]["sqnorm"][0]
+    assert all(p["h2"][0] == ref["h2"] and p["median"][0] == ref["median"] for p in parts)
+    assert all(p["sqnorm"][0] == parts[0]["sqnorm"][0] for p in parts)
     phi = np.concatenate([p["phi"] for p in parts], axis=0)
     np.testing.assert_allclose(phi, ref["phi"], rtol=0, atol=2e-6 * np.abs(ref["phi"]).max())
     np.testing.assert_allclose(parts[0]["sqnorm"][0], ref["sqnorm"], rtol=1e-5)
@@ -118,6 +116,28 @@ def test_two_rank_window_protocol(tmp_path):
     hits = list(parts[0]["hits"])
     assert hits == list(parts[1]["hits"])
     assert hits[0] == 0 and sum(hits[2:steps - 2]) >= 2 and hits[steps - 2] == 0, hits
+
+
+def test_eight_rank_window_protocol_at_c5_shard_geometry(tmp_path):
+    """World size 8, n_local = n / 8 with 128-row-aligned shards (BASELINE config 5's geometry, 131072 / 8 = 16384 rows
+    per rank, scaled down 128x so that NumPy can stand in for the kernels), window form: the exact 8-way protocol --
+    all-gathers of 8 row blocks, the table all-reduce of the window tally over 8 ranks, the radix fall-back after a jump,
+    the |phi|^2 all-reduce -- gives the oracle's bandwidth at every step on every rank."""
+    world, n, d, steps = 8, 1024, 6, 6
+    mp.spawn(_worker_window, args=(world, _free_port(), n, d, steps, str(tmp_path)), nprocs=world, join=True)
+    from oracle import svgd_oracle as orc
+    rng = np.random.default_rng(5)
+    T, G, V = rng.normal(size=(n, d)), rng.normal(size=(n, d)), 1e-3 * rng.normal(size=(n, d))
+    parts = [np.load(os.path.join(str(tmp_path), "win%d.npz" % r)) for r in range(world)]
+    for step in range(steps):
+        if step == steps - 2:
+            T = T * 2.0
+        T32 = (T + step * V).astype(np.float32).astype(np.float64)
+        ref = orc.svgd_step(T32, G.astype(np.float32).astype(np.float64), orc.AdagradState(), np.float32)
+        assert all(p["h2"][step] == ref["h2"] for p in parts), step
+    hits = list(parts[0]["hits"])
+    assert all(list(p["hits"]) == hits for p in parts)
+    assert hits[0] == 0 and sum(hits[2:steps - 2]) >= 1 and hits[steps - 2] == 0, hits
 
 
 def test_uneven_sharding_is_refused():
