@@ -138,7 +138,8 @@ struct FuseState {
   u32 done_colmax, done_hist, done_finish;
   u32 bar[2];      // k_hist_all: arrivals at its level barriers; the generation whose state has been published
   u32 pub[7];      // k_hist_all: the select state the last arrival resolved (prefix[2], rank[2] as halves, diverged)
-  u32 pad[4];
+  u32 gave_up;     // k_hist_all: a workgroup's bounded wait at a barrier ran out (the bandwidth becomes NaN)
+  u32 pad[3];
 };
 static_assert(sizeof(FuseState) == 64, "FuseState must stay 64 bytes");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;

@@ -347,9 +347,12 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
 // a few microseconds each).  Here the workgroups of the one launch (all resident: the host keeps the grid to 2 per CU) meet
 // at a barrier behind each level: an arrival counter, and the LAST workgroup to arrive resolves the level once for
 // everybody (chain_resolve with device-scope loads: the other workgroups' histogram atomics were acknowledged before they
-// drew their ticket), publishes the select state in FuseState::pub and opens the gate.  The spin is bounded: on a machine
-// where the grid is not resident the launch returns (with a wrong median) instead of hanging.
+// drew their ticket), publishes the select state in FuseState::pub and opens the gate.  The grid (at most 512 workgroups of
+// 21 KB LDS and < 128 registers) fits the chip several times over, so a workgroup that is not resident yet is waiting for
+// somebody else's kernel to leave, not for the spinning ones.  The spin is bounded all the same (~0.3 s): a workgroup that
+// gives up sets FuseState::gave_up and the step's bandwidth is written as NaN -- a wrong median is never returned.
 constexpr int HIST_ALL_MAX_N = 4096;
+constexpr int HIST_SPIN_MAX = 1 << 20;
 constexpr int HIST_BLOCKS = 2048;      // workgroups of a histogram pass (C3, every step a miss: 0.61 ms of select with 2048, 0.77 with 1024, 1.17 with 512)
 constexpr int HIST_ALL_BLOCKS = 512;   // .. of k_hist_all, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
 __device__ __forceinline__ ChainState hist_level_barrier(FuseState* fs, u32 nblk, u32 generation, const u64* hist_all, int levels,
@@ -373,8 +376,11 @@ __device__ __forceinline__ ChainState hist_level_barrier(FuseState* fs, u32 nblk
     }
     return cs;
   }
-  if (threadIdx.x == 0)
-    for (int spin = 0; spin < (1 << 20) && load_fresh(&fs->bar[1]) < generation; ++spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    int spin = 0;
+    for (; spin < HIST_SPIN_MAX && load_fresh(&fs->bar[1]) < generation; ++spin) __builtin_amdgcn_s_sleep(8);
+    if (spin == HIST_SPIN_MAX) __hip_atomic_store(&fs->gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   u32 w[7];
 #pragma unroll
@@ -403,7 +409,13 @@ __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, l
       if (h[b]) atomicAdd(&hl[b], (u64)h[b]);
     if (level + 1 < STEIN_HIST_LEVELS) cs = hist_level_barrier(fs, gridDim.x, (u32)(level - first + 1), hist_all, level + 1, st);
   }
-  if (fin.done && last_workgroup_out(fin.done, gridDim.x)) resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
+  if (fin.done && last_workgroup_out(fin.done, gridDim.x)) {
+    resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
+    if (threadIdx.x == 0 && load_fresh(&fs->gave_up)) {   // a workgroup left a barrier unopened: no median, and loudly so
+      fin.st->median = fin.st->h2 = __builtin_nanf("");
+      if (fin.h2_out) *fin.h2_out = __builtin_nanf("");
+    }
+  }
 }
 
 // one wave; hist points at this level's [2][STEIN_HIST_BINS] counters (already summed over ranks)
