@@ -45,6 +45,10 @@ __device__ unsigned long long g_dp_slow[8 * 2048];   // per wave: its slowest st
 extern "C" int stein_debug_dp_slow(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dp_slow), sizeof(g_dp_slow)) == hipSuccess ? 0 : -1;
 }
+__device__ unsigned int g_dp_trace[2048 * 64];   // per wave: [0] strips done, [1 + (k & 62)] end of its k-th strip (100 MHz ticks since the wave began; a ring of the last 62)
+extern "C" int stein_debug_dp_trace(unsigned int* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dp_trace), sizeof(g_dp_trace)) == hipSuccess ? 0 : -1;
+}
 #define DP_STRIP_BEGIN do { for (int k_ = 0; k_ < 4; ++k_) dpst_snap[k_] = dpst_acc[k_]; } while (0)
 #define DP_STRIP_END(g, s)                                                  \
   do {                                                                     \
@@ -55,13 +59,22 @@ extern "C" int stein_debug_dp_slow(unsigned long long* host_out) {
       dpst_slow[5] = (unsigned long long)(g); dpst_slow[6] = (unsigned long long)(s);          \
       dpst_slow[7] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F);     \
     }                                                                      \
+    {                                                                      \
+      const unsigned long long tr_ = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+      if ((threadIdx.x & 63) == 0) dpst_trace[(threadIdx.x >> 6) * 64 + 1 + (dpst_ntrace % 62u)] = (unsigned int)(tr_ - dpst_r0); \
+      ++dpst_ntrace;                                                       \
+    }                                                                      \
   } while (0)
 #define DP_SLOW_FLUSH(p, w, lane)                                           \
   do {                                                                     \
     if ((lane) == 0 && (p) < 256) for (int k_ = 0; k_ < 8; ++k_) g_dp_slow[((p) * 8 + (w)) * 8 + k_] = dpst_slow[k_]; \
+    if ((lane) == 0 && (p) < 256) {                                        \
+      g_dp_trace[((p) * 8 + (w)) * 64] = dpst_ntrace;                      \
+      for (int k_ = 1; k_ < 63; ++k_) g_dp_trace[((p) * 8 + (w)) * 64 + k_] = dpst_trace[(w) * 64 + k_]; \
+    }                                                                      \
   } while (0)
 #define DP_STAMP_OWN_DONE do { if (!dpst_own_t) { dpst_own_t = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); dpst_own_n = dpst_acc[5]; } } while (0)
-#define DP_STAMP_DECL unsigned long long dpst_snap[4] = {0, 0, 0, 0}, dpst_slow[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpst_own_t = 0, dpst_own_n = 0; unsigned long long dpst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpst_last = __builtin_amdgcn_s_memtime(); const unsigned long long dpst_c0 = dpst_last, dpst_r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#define DP_STAMP_DECL __shared__ unsigned int dpst_trace[8 * 64]; unsigned int dpst_ntrace = 0u; unsigned long long dpst_snap[4] = {0, 0, 0, 0}, dpst_slow[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpst_own_t = 0, dpst_own_n = 0; unsigned long long dpst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpst_last = __builtin_amdgcn_s_memtime(); const unsigned long long dpst_c0 = dpst_last, dpst_r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
 #define DP_STAMP(k)                                                        \
   do {                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                     \
@@ -83,6 +96,28 @@ extern "C" int stein_debug_dp_slow(unsigned long long* host_out) {
       atomicAdd(&g_dp_stamps[9], dpst_acc[6]); atomicAdd(&g_dp_stamps[10], dpst_acc[7]); \
     }                                                                      \
   } while (0)
+#elif defined(STEIN_WGEND)
+// the lightest probe: begin and end (100 MHz ticks) of every wave of the otherwise shipped kernel, one plain store per wave
+__device__ unsigned long long g_dp_wave_span[2 * 2048];
+extern "C" int stein_debug_dp_span(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dp_wave_span), sizeof(g_dp_wave_span)) == hipSuccess ? 0 : -1;
+}
+#define DP_STAMP_DECL const unsigned long long dpst_r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#define DP_STAMP(k) do {} while (0)
+#define DP_STAMP_COUNT(k) do {} while (0)
+#define DP_STAMP_FLUSH(lane) do {} while (0)
+#define DP_STAMP_WG(p, w, lane)                                            \
+  do {                                                                     \
+    if ((lane) == 0 && (p) < 256) {                                        \
+      const unsigned long long r1_ = __builtin_amdgcn_s_memrealtime();     \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                  \
+      g_dp_wave_span[2 * ((p) * 8 + (w))] = dpst_r0; g_dp_wave_span[2 * ((p) * 8 + (w)) + 1] = r1_; \
+    }                                                                      \
+  } while (0)
+#define DP_STAMP_OWN_DONE do {} while (0)
+#define DP_STRIP_BEGIN do {} while (0)
+#define DP_STRIP_END(g, s) do {} while (0)
+#define DP_SLOW_FLUSH(p, w, lane) do {} while (0)
 #else
 #define DP_STAMP_DECL do {} while (0)
 #define DP_STAMP(k) do {} while (0)

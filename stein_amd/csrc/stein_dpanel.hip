@@ -390,7 +390,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         cur = nxt;
         if (diag) { DP_STAMP(6); DP_STAMP_COUNT(7); } else DP_STAMP(3);
         DP_STAMP_COUNT(5);
-        DP_STRIP_END(g, s);
+        DP_STRIP_END(2 * unit + half, s);
         if (!more) break;
         s = s1;
         s1 = s2;

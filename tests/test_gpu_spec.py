@@ -125,3 +125,25 @@ def test_last_workgroup_tickets_match_separate_launches(cuda, seed):
             assert float(fused.h2) == float(staged.h2), (n, d, step)
             assert torch.equal(pf, ps), (n, d, step)
             assert float(fused.sqnorm) == float(staged.sqnorm), (n, d, step)
+
+
+@pytest.mark.parametrize("n,d,dtype", [(513, 5, torch.float32), (1000, 33, torch.float32), (2049, 64, torch.bfloat16),
+                                        (4096, 128, torch.bfloat16)])
+def test_one_launch_select_without_the_window(cuda, n, d, dtype):
+    """window=False, 512 < n <= 4096: every step takes the one-launch chained radix select (k_hist_all: all levels in one
+    launch, workgroups meeting at in-launch barriers, the last arrival resolving a level for all of them; the level-0 counts
+    come from the distance kernel or, with skip_l0 clear, from the launch itself).  Bandwidth, phi and |phi|^2 equal the
+    staged calls' (separate k_hist / k_resolve launches) bit for bit at every step, for odd and even n^2."""
+    g = torch.Generator(device="cpu").manual_seed(7 * n + d)
+    fused = SvgdEngine(n, d, device=cuda, dtype=dtype, window=False, small=False)
+    staged = SvgdEngine(n, d, device=cuda, dtype=dtype, small=False)
+    T = torch.randn(n, d, generator=g).to(cuda)
+    for step in range(5):
+        G = torch.randn(n, d, generator=g).to(cuda).to(dtype)
+        Tq = (T * (1.0 + 0.7 * step)).to(dtype)
+        pf = fused.compute_phi(Tq, G).clone()
+        ps = _staged(staged, Tq, G).clone()
+        torch.cuda.synchronize()
+        assert float(fused.h2) == float(staged.h2) and float(fused.h2) > 0.0, (step, float(fused.h2), float(staged.h2))
+        assert torch.equal(pf, ps) and float(fused.sqnorm) == float(staged.sqnorm), step
+        assert _spec_state(fused)["hit"] == 0
