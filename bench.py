@@ -512,8 +512,9 @@ def main():
         stored = tiles * 128 * 128 * 4.0 if n % 128 == 0 and nl % 128 == 0 else None
         dflop = 2.0 * nl * n * d * (0.5 if world == 1 else 1.0)
         out["distance_pass"] = {
-            "kernel": "k_distance_panel (operand panel in LDS, strips streamed from L2)" if (nl // 128) * (n // 32) >= 16384 and d <= 256
-                      and n % 128 == 0 and nl % 128 == 0 else "k_distance_x3 (one 128 x 128 tile per workgroup)",
+            "kernel": ("k_distance_x3 (one 128 x 128 tile per workgroup)" if not ((nl // 128) * (n // 32) >= 16384 and n % 128 == 0 and nl % 128 == 0)
+                       else "k_distance_panel (operand panel in LDS, strips streamed from L2)" if d <= (512 if wl.get("bf16") else 256)
+                       else "k_distance_panel_deep (the panel in LDS a chunk of K at a time, strips streamed from L2)"),
             "ms_per_launch": d_ms, "bound": "hbm",
             "stored_bytes": stored, "achieved_write_GBps": stored / (d_ms * 1e-3) / 1e9 if stored else None,
             "peak_GBps": 8000.0, "frac_of_hbm_peak": stored / (d_ms * 1e-3) / 8e12 if stored else None,
@@ -521,7 +522,7 @@ def main():
             "frac_of_16bit_mfma_peak": nprod * dflop / (d_ms * 1e-3) / PEAK_16BIT_MFMA,
             "hbm_bytes_measured": pmc_ent.get("k_distance_hbm_bytes") if world == 1 else None,
             "note": "the pass writes D once (algorithmic bytes = stored bytes) and executes %d x n^2 d MFMA flops with the "
-                    "symmetry; both floors are ~0.085 ms at C3" % nprod}
+                    "symmetry; at C3 a plain fill writes these bytes in 0.083 ms and the MFMAs need 0.11 ms at the sustained clock" % nprod}
     if world > 1:
         out["collectives"] = {"issued_by": {"native": "libsteinhip (own RCCL communicator, stein_rank_step: one C call per step)",
                                             "torch": "torch.distributed (backend %s) between the rank segments" % dist.get_backend(group)}[res["comm"]],

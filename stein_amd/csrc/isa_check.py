@@ -1,5 +1,5 @@
 """Build-time audit of the gfx950 assembly of the kernels that stream memory through inline asm with hand-counted waits
-(k_phi_x3fs in stein_x3.hip, k_distance_panel in stein_dpanel.hip).  hipcc neither counts nor pads what is inside an
+(k_phi_x3fs in stein_x3.hip, k_distance_panel and k_distance_panel_deep in stein_dpanel.hip).  hipcc neither counts nor pads what is inside an
 `asm` statement (cdna_hip_programming.md 5.7), so three things that it normally guarantees are checked here instead, on the
 `.s` that -save-temps leaves beside the object; __graft_entry__.build() fails when one of them is violated:
 
@@ -19,8 +19,8 @@ usage: python isa_check.py file.s [kernel-name-prefix ...]
 import re
 import sys
 
-DEFAULT_PREFIXES = ("_Z10k_phi_x3fs", "_Z16k_distance_panel")
-PATH_PREFIXES = ("_Z16k_distance_panel",)
+DEFAULT_PREFIXES = ("_Z10k_phi_x3fs", "_Z16k_distance_panel", "_Z21k_distance_panel_deep")
+PATH_PREFIXES = ("_Z16k_distance_panel", "_Z21k_distance_panel_deep")
 _VMEM = re.compile(r"\b(global_load\w*|global_atomic\w*|global_store\w*|buffer_load\w*|buffer_store\w*)\b")
 _SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
 _VREG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")

@@ -16,12 +16,11 @@
 //   * the two waves of a SIMD drift into opposite phases -- one wave's epilogue (VALU, LDS, stores) runs under the other
 //     wave's MFMAs -- because nothing ties them together; loads and stores of a wave share one in-order counter on gfx950,
 //     so the waits below count the stores that sit between a load and its use.
-// A workgroup's strips are a contiguous range of the row-major strip order (cost-balanced, a panel switch is priced in),
-// and workgroups that share an XCD get neighbouring ranges: the same column strips, a row tile apart, meet in its L2.
 //
-// Restrictions (the caller falls back to k_distance_x3): n, n_local and row0 multiples of 128; NP * K / 32 <= 16 (the panel
-// fits 128 KB: d <= 256 for fp32 inputs); no level-0 histogram in the epilogue -- a step without a median window gets it from
-// a k_hist<0> pass instead (the kernel clears SpecState::skip_l0 itself).
+// Restrictions (the caller falls back to k_distance_x3): n, n_local and row0 multiples of 128; no level-0 histogram in the
+// epilogue -- a step without a median window gets it from a k_hist<0> pass instead (the kernel clears SpecState::skip_l0
+// itself).  NP * K / 32 <= 16 (the panel fits 128 KB: d <= 256 for fp32 inputs) for k_distance_panel; a longer K goes to
+// k_distance_panel_deep (below), which keeps a chunk of the panel in LDS at a time.
 //
 // SYM (single rank): only strips on and above the diagonal exist; off-diagonal tiles count twice (weight 2) and are
 // stored once (the contraction reads the others transposed).  The four strips of a diagonal tile store entry by entry:
@@ -49,29 +48,13 @@ constexpr int DP_LDS = DP_PANEL + 8 * DP_STAGE + 8 * DP_QBYTES;   // 157,696 of 
 // share a row and take its strips INTERLEAVED (member m: strips m, m + M, m + 2 M, ...); with more rows than workgroups a
 // workgroup takes rows p, p + G, ... one after the other.  Workgroups that share an XCD hold neighbouring rows (xcd_remap),
 // so at any time all of an XCD's workgroups -- members of one row and of its neighbours alike -- sweep the same few column
-// strips: one wave pulls a strip's operand into the XCD's L2 and up to 31 others find it there.  That matters more than
-// anything else about this kernel: it moves ~1 GB of operand fragments per launch at C3, and with every workgroup on a
-// contiguous QUARTER of its row (round 3's first form) half of that still came from beyond the L2 (rocprofv3: 0.53 GB of
-// fetches + 0.54 GB of D stores in 0.21 ms = the fabric's whole bandwidth, and the D stores of some XCDs then stalled for
-// 100-200 us at a time).  Inside a workgroup the strips are dealt to the waves one by one by a counter in LDS.
-// (Also tried and dropped, round 3: strips drawn from per-row counters in global memory by teams of four workgroups, with
-// work stealing once a team had run dry: 0.206-0.219 ms at C3 against 0.192-0.204 for contiguous pieces.)
-
-// Who works on what.  A segment = one row tile's run of column strips = one operand panel.
-//   row block (not SYM): segment g = row tile g, strips [0, 4 tiles_n): all equally long.
-//   SYM: the rows of the triangle are folded into "virtual rows" of equal length: virtual row v = row v (strips [4 v, 4 N)),
-//        then row N - 1 - v (strips [4 (N - 1 - v), 4 N)): 4 N + 4 strips whatever v (the middle row of an odd N stands alone).
-//        Segment 2 v is the long part, 2 v + 1 the short one.
-// A workgroup takes a contiguous, equally priced piece of this order (a panel switch is priced in), and workgroups that
-// share an XCD take neighbouring pieces (xcd_remap).  With equally long (virtual) rows, workgroup p and workgroup
-// p + (workgroups per row) sit at the same place of neighbouring rows and stream the same column strips at the same time:
-// one of them pulls a strip's operand into the XCD's L2, the others find it there.  (Dealt in plain row order the
-// triangle's rows shrink, the workgroups of an XCD drift apart along the columns, every one of them streams alone from
-// beyond the L2, and the XCDs holding the middle rows took 1.5 times as long as the others.)  Inside a workgroup the strips
-// of a piece are dealt to the waves one by one by a counter in LDS.
-// (Tried and dropped, round 3: teams of four workgroups per virtual row drawing strips from a counter in global memory,
-// with work stealing once a team had run dry -- 0.206-0.219 ms at C3 against 0.192 for this form on like boxes; what holds
-// a launch up is not the deal but its D stores, see DESIGN.md.)
+// strips: one wave pulls a strip's operand into the XCD's L2 and up to 31 others find it there.  The kernel moves ~1 GB of
+// operand fragments per launch at C3; with every workgroup on a contiguous QUARTER of its row (round 3's first form) 262 MB
+// of that came from beyond the L2, interleaved 102 MB (rocprofv3 FETCH_SIZE) -- at the same launch time: what a wave
+// waits for is not its operand but the acknowledgement of its own D stores (one in-order vmcnt).
+// Inside a workgroup the strips are dealt to the waves one by one by a counter in LDS.
+// (Tried and dropped, round 3: strips drawn from per-row counters in global memory by teams of four workgroups, with
+// work stealing once a team had run dry: 0.206-0.219 ms at C3 against 0.192-0.204 for this form on like boxes.)
 template <bool SYM>
 __device__ __forceinline__ int dp_segments(int tiles_m, int tiles_n) { return SYM ? 2 * ((tiles_n + 1) / 2) : tiles_m; }
 template <bool SYM>
@@ -324,66 +307,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         DP_STAMP(2);
         stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
-        const int c32 = cfirst + members * s;
-        float* __restrict__ dt = D + ((size_t)I * ntc + c32) * DT_ELEMS;
-        const bool diag = SYM && (c32 >> 2) == I;
-        const u32 wt = SYM ? 2u : 1u;
-        // a strip of the diagonal tile stores entry by entry behind the same staging: (i, j) for i <= j and, for i < j, the
-        // same value at its mirror place (j, i); the entries below the diagonal belong to the strip that holds their mirror
-        const int d4 = c32 & 3;
-        float* __restrict__ dmir = D + ((size_t)I * ntc + 4 * I) * DT_ELEMS;      // the diagonal tile's first 32 columns
-        const int sr = lane >> 3, sc4 = (lane & 7) * 4;                          // staged row / first column of this lane
-        const int lane_dir = sr * 32 + sc4, lane_dij = sr - sc4;                  // (staged-row layout: direct stores)
-        const int lane_mir = lq * 128 + li, lane_dji = 4 * lq - li;               // (accumulator layout: mirror stores)
-#pragma unroll
-        for (int ib = 0; ib < 8; ++ib) {
-#pragma unroll
-          for (int jb = 0; jb < 2; ++jb) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[ib][jb][e], nts, ri[ib] + rj[jb][e]);
-            if (window && !diag) { const u32 w4[4] = {wt, wt, wt, wt}; dp_count4<true>(sx, v, w4, wt, lane); }
-            *reinterpret_cast<float4*>(stg + li * DP_PITCH + jb * 64 + lq * 16) = make_float4(v[0], v[1], v[2], v[3]);
-            if (diag && ib < 2 * d4 + 2) {
-              // mirror places, straight from the accumulator layout: lane = row i, so the 16 lanes of a quarter wave write 64
-              // contiguous bytes of mirror row j.  (From the staged rows, where neighbouring lanes hold neighbouring COLUMNS,
-              // every lane's 4 bytes were a memory transaction of their own: ~8000 per strip, ~150 us, during which the
-              // other waves of the CU could not issue their loads either.)
-              const int dji = 32 * d4 + 16 * jb - 16 * ib + lane_dji;               // j - i at e = 0
-              float* __restrict__ pm = dmir + (size_t)(ib >> 1) * DT_ELEMS + (d4 * 32 + jb * 16) * 32 + ((16 * ib) & 31);
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (dji + e > 0) pm[lane_mir + e * 32] = v[e];
-            }
-          }
-          const float4 x0 = *reinterpret_cast<const float4*>(stg + sr * DP_PITCH + sc4 * 4);
-          const float4 x1 = *reinterpret_cast<const float4*>(stg + (8 + sr) * DP_PITCH + sc4 * 4);
-          if (!diag) {
-            DP_STORE16(dt + ib * 512 + lane * 4, x0);          // rows 16 ib .. + 7: 1 KB contiguous
-            DP_STORE16(dt + ib * 512 + 256 + lane * 4, x1);    // rows 16 ib + 8 .. + 15
-          } else if (ib < 2 * d4 + 2) {                                          // (blocks below the diagonal block: nothing)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float xs[4] = {h ? x1.x : x0.x, h ? x1.y : x0.y, h ? x1.z : x0.z, h ? x1.w : x0.w};
-              // row i = i0 + sr and column j = 32 d4 + sc4 + e inside the tile; everything but lane_dir / dij is
-              // wave-uniform (addresses written out this way keep the diagonal path to a handful of registers)
-              const int i0 = 16 * ib + 8 * h;
-              float* __restrict__ pd = dt + i0 * 32;
-              const int dij = i0 - 32 * d4 + lane_dij;                           // i - j at e = 0
-              u32 w4[4];
-              // the lane's four columns lie all above the diagonal (one 16-byte store, as everywhere else), all below it
-              // (nothing), or straddle it (entry by entry; a handful of lanes).  Sixty-four single-entry stores 16 bytes apart
-              // per instruction made a diagonal strip take ~100 us: the waves that drew them held up their whole team.
-              if (dij < 0) *reinterpret_cast<float4*>(pd + lane_dir) = make_float4(xs[0], xs[1], xs[2], xs[3]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                w4[e] = dij < e ? 2u : (dij == e ? 1u : 0u);
-                if (w4[e] && dij >= 0) pd[lane_dir + e] = xs[e];
-              }
-              if (window) dp_count4<false>(sx, xs, w4, 0u, lane);
-            }
-          }
-        }
+#include "stein_dpanel_epilogue.inc"
         regular = !diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
         request_norms(snext);                      // ("memory": the strip's stores are issued before this point)
@@ -412,6 +336,164 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_distance_panel_deep: the same pass for a K that does not fit the LDS panel (NP * K / 32 > 16: d > 256 for fp32 inputs,
+// BASELINE config 4's d = 2001).  The panel holds KC = 16 / NP k tiles at a time.  An accumulator tile has to live
+// through all of K, so the eight waves take one strip each (a "round", dealt statically: the rounds are barrier-bound anyway),
+// and walk K chunk by chunk in step: barrier, all waves copy the panel's next chunk to LDS, barrier, every wave multiplies
+// its eight (or sixteen) k tiles -- the strip operand streams through the same register ring as in k_distance_panel, across
+// the chunk boundaries -- and after the last chunk runs the same epilogue.  The panel copy is exposed once per chunk
+// (128 KB from L2 against 8 x 384 MFMAs per wave); the compiler's own waits for those copies drain the ring at every
+// boundary, so the hand-counted waits behind a boundary only ever see fewer operations in flight than they allow.
+// ------------------------------------------------------------------------------------------------
+template <bool SYM, int NP>
+__global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16* __restrict__ T3, int ntk,
+                                                                       const float* __restrict__ r, float* __restrict__ D,
+                                                                       int row0, int tiles_m, int tiles_n, long ldD,
+                                                                       const float* __restrict__ two_s,
+                                                                       SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
+  constexpr int LPS = 2 * NP;
+  constexpr int KC = 16 / NP;                  // k tiles of the panel in LDS at a time
+  constexpr int W_LATE = 3 * LPS;              // the loads of the three k tiles behind the one waited for stay in flight
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  unsigned char* const panel = smem;
+  unsigned char* const stg = smem + DP_PANEL + w * DP_STAGE;
+  const long ntc = ldD >> 5;
+  const int groups = (ntk + DP_RING - 1) / DP_RING, nchunks = (ntk + KC - 1) / KC;
+  const float nts = -*two_s;
+
+  DpWin sx;
+  sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u; sx.qn = 0u; sx.over = 0u;
+  sx.q = reinterpret_cast<u64*>(smem + DP_PANEL + 8 * DP_STAGE + w * DP_QBYTES);
+  bool window = false;
+  if (spec) {
+    const u32 lk = spec->lo_key, wd = spec->width;
+    window = wd != 0u;
+    if (window) { sx.lo = lk & 0x7fffffffu; sx.width = wd; }
+    else if (blockIdx.x == 0 && t == 0) spec->skip_l0 = 0u;   // (no level-0 histogram here either)
+  }
+
+  // the workgroup's share of the strip order: as in k_distance_panel
+  const int G = gridDim.x, p = xcd_remap(blockIdx.x, G);
+  const int U = SYM ? (tiles_n + 1) / 2 : tiles_m;
+  int unit, member, members, unit_step;
+  if (U >= G) { unit = p; member = 0; members = 1; unit_step = G; }
+  else {
+    const int M = G / U, big = G - U * M;
+    if (p < big * (M + 1)) { unit = p / (M + 1); member = p % (M + 1); members = M + 1; }
+    else { const int q = p - big * (M + 1); unit = big + q / M; member = q % M; members = M; }
+    unit_step = U;
+  }
+  const u32 aoff = (u32)lane * 16u, aoff1 = aoff + (u32)XPLANE;
+  const int li = lane & 15, lq = lane >> 4;
+  u32x4 ring[DP_RING][2][3];
+
+  for (; unit < U; unit += unit_step)
+  for (int half = 0; half < (SYM ? 2 : 1); ++half) {
+    int I, len;
+    dp_segment<SYM>(SYM ? 2 * unit + half : unit, tiles_n, I, len);
+    const int se = len > member ? (len - member + members - 1) / members : 0;   // this workgroup's strips: member + members k
+    if (se <= 0) continue;
+    const int cfirst = (SYM ? 4 * I : 0) + member;
+    auto strip_base = [&](int strip) {
+      const long j0 = 32l * (cfirst + members * strip);
+      return reinterpret_cast<const u16*>(dp_uniform(T3 + ((size_t)(j0 >> 7) * ntk * 3) * XTILE_E + ((j0 & 127) >> 4) * 512));
+    };
+    // (asm statements with vector-memory instructions open with s_nop 4: see k_distance_panel)
+    auto request = [&](const u16* sbase, int kt, u32x4 (&slot)[2][3]) {
+      const u16* src = sbase + (size_t)(kt < ntk ? kt : ntk - 1) * 3 * XTILE_E;
+      if constexpr (NP == 2) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %5, %6\n\t"
+                     "global_load_dwordx4 %2, %4, %6 offset:1024\n\tglobal_load_dwordx4 %3, %5, %6 offset:1024"
+                     : "=&v"(slot[0][0]), "=&v"(slot[0][1]), "=&v"(slot[1][0]), "=&v"(slot[1][1])
+                     : "v"(aoff), "v"(aoff1), "s"(src));
+      } else {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                     : "=&v"(slot[0][0]), "=&v"(slot[1][0]) : "v"(aoff), "s"(src));
+      }
+    };
+    const int rounds = (se + 7) / 8;
+    int s = w;                                   // round k: strip 8 k + w
+    const u16* cur = strip_base(s < se ? s : 0);
+    if (s < se) {
+#pragma unroll
+      for (int u = 0; u < DP_RING; ++u) request(cur, u, ring[u]);
+    }
+    for (int round = 0; round < rounds; ++round, s += 8) {
+      const bool active = s < se;                // (wave-uniform; once false it stays false)
+      const int snext = s + 8 < se ? s + 8 : (active ? s : 0);   // (no next strip: the trailing requests re-read this one)
+      const u16* nxt = strip_base(snext);
+      f32x4 acc[8][2];
+#pragma unroll
+      for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                         // everybody is done with the chunk in LDS
+        {
+          // LDS-direct loads (global_load_lds_dwordx4: a wave's 64 x 16 bytes land at a wave-uniform LDS base + 16 lane, which
+          // is the panel's layout): the accumulators and the ring are live here and there are no registers for the pieces.
+          // Scalar base + one 32-bit lane offset, so that the sixteen addresses cost no vector registers either.
+          typedef const __attribute__((address_space(1))) void* gptr_t;
+          typedef __attribute__((address_space(3))) void* lptr_t;
+          const u16* rowtile = T3 + ((size_t)(row0 / 128 + I) * ntk * 3) * XTILE_E + w * 512;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {         // (k tiles past the end repeat the last one: nobody reads them)
+            const int ktq = c * KC + q / NP;
+            const char* pl = reinterpret_cast<const char*>(dp_uniform(rowtile + ((size_t)(ktq < ntk ? ktq : ntk - 1) * 3 + q % NP) * XTILE_E));
+            __builtin_amdgcn_global_load_lds((gptr_t)(pl + aoff), (lptr_t)(panel + q * XPLANE + w * 1024), 16, 0, 0);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (active) {
+          for (int gl = 0; gl < KC / DP_RING; ++gl) {
+            const int g = c * (KC / DP_RING) + gl;
+            if (g >= groups) break;
+            const bool last = g + 1 >= groups;
+#pragma unroll
+            for (int u = 0; u < DP_RING; ++u) {
+              const int kt = g * DP_RING + u;
+              stream_wait<W_LATE>();
+              if (kt < ntk) dp_step<NP>(panel + (kt - c * KC) * NP * XPLANE + aoff, ring[u], acc);
+              request(last ? nxt : cur, last ? u : kt + DP_RING, ring[u]);
+            }
+          }
+        }
+      }
+      if (active) {
+        // the norms of the strip's rows and columns: plain loads, here (eight registers each that the K loop needs; the
+        // compiler's wait for them also lands the next strip's first requests -- the chunk boundary behind the epilogue
+        // would have done that anyway)
+        float ri[8];
+        f32x4g rj[2];
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib) ri[ib] = r[row0 + 128 * I + 16 * ib + li];
+        {
+          const float* rb = r + 32l * (cfirst + members * s) + 4 * lq;
+          rj[0] = *reinterpret_cast<const f32x4g*>(rb);
+          rj[1] = *reinterpret_cast<const f32x4g*>(rb + 16);
+        }
+#include "stein_dpanel_epilogue.inc"
+        (void)diag;
+        if (window && sx.qn >= (u32)(DP_QCAP / 2)) dp_flush(sx, spec, spec_buf, lane);
+        cur = nxt;
+      }
+    }
+    stream_wait<0>();                            // the trailing re-reads land before their registers move on
+  }
+  if (window) {
+    dp_flush(sx, spec, spec_buf, lane);
+    if (lane == 0) {
+      if (sx.below) atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + ((blockIdx.x * 8 + w) % SPEC_SLOTS) * 8),
+                              (unsigned long long)sx.below);
+      if (sx.over) spec->overflow = 1u;
+    }
+  }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -421,7 +503,7 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
   const int64_t ntk = L.x3_dk / 32;
   if (level0_only) return false;                                   // the caller wants the level-0 histogram from the epilogue
   if ((n & 127) || (n_local & 127) || (row0 & 127)) return false;
-  if (np * ntk > 16) return false;                                 // the panel must fit 128 KB of LDS
+  // (np * ntk > 16: the panel does not fit 128 KB of LDS -> k_distance_panel_deep walks K in chunks)
   // below ~16 strips per wave the panel loads and the ragged tail outweigh the overlap (and the launch fits one
   // round of the tile kernel anyway)
   return any_size || (n_local / 128) * (n / 32) >= 256 * 8 * 8;
@@ -441,9 +523,15 @@ int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, c
     HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     ncu = v > 0 ? v : 256;
   }
-#define DP_LAUNCH(SYM, NP) hipLaunchKernelGGL((k_distance_panel<SYM, NP>), dim3((unsigned)ncu), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf)
-  if (stein_x3_kind(dtype) == 1) { if (symmetric) DP_LAUNCH(true, 1); else DP_LAUNCH(false, 1); }
-  else { if (symmetric) DP_LAUNCH(true, 2); else DP_LAUNCH(false, 2); }
+  const int np = stein_x3_kind(dtype);
+#define DP_LAUNCH(KERNEL, SYM, NP) hipLaunchKernelGGL((KERNEL<SYM, NP>), dim3((unsigned)ncu), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf)
+  if (np * ntk <= 16) {
+    if (np == 1) { if (symmetric) DP_LAUNCH(k_distance_panel, true, 1); else DP_LAUNCH(k_distance_panel, false, 1); }
+    else { if (symmetric) DP_LAUNCH(k_distance_panel, true, 2); else DP_LAUNCH(k_distance_panel, false, 2); }
+  } else {   // K in chunks of 16 / np k tiles
+    if (np == 1) { if (symmetric) DP_LAUNCH(k_distance_panel_deep, true, 1); else DP_LAUNCH(k_distance_panel_deep, false, 1); }
+    else { if (symmetric) DP_LAUNCH(k_distance_panel_deep, true, 2); else DP_LAUNCH(k_distance_panel_deep, false, 2); }
+  }
 #undef DP_LAUNCH
   LAUNCH_CHECK("k_distance_panel");
   return STEIN_OK;

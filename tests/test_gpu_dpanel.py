@@ -33,7 +33,12 @@ def _fp64_dist(T, rows=None):
 
 
 @pytest.mark.parametrize("n,d,dtype", [(1024, 256, torch.float32), (768, 200, torch.float32), (512, 100, torch.float32),
-                                       (640, 33, torch.float32), (1024, 128, torch.bfloat16), (512, 300, torch.bfloat16)])
+                                       (640, 33, torch.float32), (1024, 128, torch.bfloat16), (512, 300, torch.bfloat16),
+                                       # K beyond the LDS panel (k_distance_panel_deep: K in chunks of 8 / 16 k tiles): two chunks
+                                       # with a short last one, three chunks with a one-tile last one, BASELINE config 4's
+                                       # d = 2001 (eight chunks), bf16 with two chunks
+                                       (1024, 300, torch.float32), (640, 520, torch.float32), (512, 2001, torch.float32),
+                                       (512, 600, torch.bfloat16)])
 def test_panel_symmetric_matches_tile_kernel_and_fp64(cuda, n, d, dtype):
     T, G = _inputs(n, d, cuda, dtype)
     eng = SvgdEngine(n, d, device=cuda, x3=True, dtype=dtype, small=False)
@@ -64,7 +69,8 @@ def test_panel_symmetric_matches_tile_kernel_and_fp64(cuda, n, d, dtype):
     assert (out["panel"] - out["tiles"]).abs().max().item() <= 2e-6 * scale
 
 
-@pytest.mark.parametrize("n,d,row0,nl", [(1024, 256, 256, 512), (1536, 96, 1280, 256), (512, 256, 0, 512)])
+@pytest.mark.parametrize("n,d,row0,nl", [(1024, 256, 256, 512), (1536, 96, 1280, 256), (512, 256, 0, 512),
+                                         (1024, 400, 256, 512), (1280, 1030, 1152, 128)])   # (the last two: K in chunks)
 def test_panel_row_block_matches_fp64(cuda, n, d, row0, nl):
     """non-symmetric row block [row0, row0 + nl) of the n columns, every tile stored"""
     T, G = _inputs(n, d, cuda, seed=3)
@@ -88,11 +94,11 @@ def test_panel_row_block_matches_fp64(cuda, n, d, row0, nl):
     assert (mats["panel"] - mats["tiles"]).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("sym", [True, False])
-def test_panel_feeds_the_median_window(cuda, sym):
+@pytest.mark.parametrize("sym,d", [(True, 64), (False, 64), (True, 320), (False, 700)])   # (d > 256: k_distance_panel_deep)
+def test_panel_feeds_the_median_window(cuda, sym, d):
     """Window form of the staged calls on one rank: the panel kernel's epilogue counts the entries below the window and
     collects those inside it; tally + pick then deliver the exact order statistics of the kernel's own image."""
-    n, d = 1024, 64
+    n = 1024
     T, G = _inputs(n, d, cuda, seed=5)
     eng = SvgdEngine(n, d, device=cuda, x3=True, small=False)
     for _ in range(4):      # fused steps give the predictor its history (the particles drift a little per step)
