@@ -5,6 +5,7 @@ usage: python scratch/dist_ab.py [c3] [c5]
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stein_amd import _lib
+if os.environ.get("STAMPLIB"): _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ["STAMPLIB"])   # a scratch/build_variant.py library
 from stein_amd.engine import SvgdEngine, HipStages
 from stein_amd.optimizers import AdagradGradientDescent
 what = sys.argv[1:] or ["c3", "c5"]

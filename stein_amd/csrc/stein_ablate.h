@@ -21,9 +21,14 @@ __device__ unsigned long long g_dp_stamps[12];   // k_distance_panel, summed ove
                                                 // [1] LDS fragment reads + MFMAs, [2] issuing the next requests,
                                                 // [3] epilogue, [4] panel switches (barriers + load), [5] strips, [6] waves,
                                                 // [7] shader-clock ticks and [8] 100 MHz real-time ticks of the waves' lifetimes
+__device__ unsigned long long g_dp_stamps_w[2048 * 12];   // the same per wave (workgroup * 8 + wave): what the kernel writes
 extern "C" int stein_debug_dp(unsigned long long* host_out, int reset) {
-  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dp_stamps), sizeof(g_dp_stamps)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dp_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  static unsigned long long all[2048 * 12];
+  if (host_out) {
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_dp_stamps_w), sizeof(all)) != hipSuccess) return -1;
+    for (int k = 0; k < 12; ++k) { host_out[k] = 0; for (int w = 0; w < 2048; ++w) host_out[k] += all[w * 12 + k]; }
+  }
+  if (reset) { for (int i = 0; i < 2048 * 12; ++i) all[i] = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dp_stamps_w), all, sizeof(all)) != hipSuccess) return -1; }
   return 0;
 }
 __device__ unsigned long long g_dp_wg[6 * 256];   // per logical workgroup id: start, end (100 MHz ticks) of wave 0, its strips, its shader-clock ticks, the time its own segments were done, its strips up to then
@@ -85,15 +90,19 @@ extern "C" int stein_debug_dp_trace(unsigned int* host_out) {
     __builtin_amdgcn_sched_barrier(0);                                     \
   } while (0)
 #define DP_STAMP_COUNT(k) do { dpst_acc[k] += 1ull; } while (0)
+// (plain stores into per-wave slots, summed by stein_debug_dp on the host: with atomicAdd onto twelve shared words, every wave's
+// exit queued a dozen same-address atomics in front of the loads of the waves still running -- a 100-200 us tail that was the
+// stamp code's, not the kernel's)
 #define DP_STAMP_FLUSH(lane)                                               \
   do {                                                                     \
     if ((lane) == 0) {                                                     \
-      for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_dp_stamps[k_], dpst_acc[k_]); \
-      atomicAdd(&g_dp_stamps[6], 1ull);                                    \
+      unsigned long long* o_ = g_dp_stamps_w + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 12; \
+      for (int k_ = 0; k_ < 6; ++k_) o_[k_] += dpst_acc[k_];               \
+      o_[6] += 1ull;                                                       \
       const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime(); \
       __builtin_amdgcn_s_waitcnt(0xC07F);                                  \
-      atomicAdd(&g_dp_stamps[7], c1_ - dpst_c0); atomicAdd(&g_dp_stamps[8], r1_ - dpst_r0); \
-      atomicAdd(&g_dp_stamps[9], dpst_acc[6]); atomicAdd(&g_dp_stamps[10], dpst_acc[7]); \
+      o_[7] += c1_ - dpst_c0; o_[8] += r1_ - dpst_r0;                       \
+      o_[9] += dpst_acc[6]; o_[10] += dpst_acc[7];                          \
     }                                                                      \
   } while (0)
 #elif defined(STEIN_WGEND)

@@ -50,8 +50,8 @@ constexpr int DP_LDS = DP_PANEL + 8 * DP_STAGE + 8 * DP_QBYTES;   // 157,696 of 
 // so at any time all of an XCD's workgroups -- members of one row and of its neighbours alike -- sweep the same few column
 // strips: one wave pulls a strip's operand into the XCD's L2 and up to 31 others find it there.  The kernel moves ~1 GB of
 // operand fragments per launch at C3; with every workgroup on a contiguous QUARTER of its row (round 3's first form) 262 MB
-// of that came from beyond the L2, interleaved 102 MB (rocprofv3 FETCH_SIZE) -- at the same launch time: what a wave
-// waits for is not its operand but the acknowledgement of its own D stores (one in-order vmcnt).
+// of that came from beyond the L2, interleaved 102 MB (rocprofv3 FETCH_SIZE) -- at the same launch time: the launch is
+// bound by the clock the chip holds while it writes D, not by where the operand comes from.
 // Inside a workgroup the strips are dealt to the waves one by one by a counter in LDS.
 // (Tried and dropped, round 3: strips drawn from per-row counters in global memory by teams of four workgroups, with
 // work stealing once a team had run dry: 0.206-0.219 ms at C3 against 0.192-0.204 for this form on like boxes.)
