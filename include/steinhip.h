@@ -71,8 +71,9 @@ enum {
                                 whole symmetric matrix, as stein_distance_block(STEIN_STAGE_SYMMETRIC) with x3_planes
                                 leaves it; entries of the other tiles are read from their mirror images */
   STEIN_STAGE_TILES = 4,     /* stein_distance_block*: always the per-tile kernel (one 128 x 128 tile per workgroup).  Without
-                                it, large blocks whose operand panel fits LDS (n, n_local, row0 multiples of 128; d <= 256
-                                for fp32 inputs; split path) take the panel-resident kernel (stein_amd/csrc/stein_dpanel.hip):
+                                it, large blocks on the split path whose n, n_local and row0 are multiples of 128 take the
+                                panel-resident kernels (stein_amd/csrc/stein_dpanel.hip: the operand panel of a row tile in
+                                LDS, whole for d <= 256 with fp32 inputs / 512 with bf16, a chunk of K at a time beyond that):
                                 the same formula, entries may differ from the per-tile kernel's in the last bit */
   STEIN_STAGE_PANEL = 8      /* stein_distance_block*: take the panel-resident kernel whenever its restrictions hold, however
                                 small the block (tests) */
