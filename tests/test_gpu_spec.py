@@ -128,7 +128,7 @@ def test_last_workgroup_tickets_match_separate_launches(cuda, seed):
 
 
 @pytest.mark.parametrize("n,d,dtype", [(513, 5, torch.float32), (1000, 33, torch.float32), (2049, 64, torch.bfloat16),
-                                        (4096, 128, torch.bfloat16)])
+                                        (4096, 128, torch.bfloat16), (4224, 9, torch.float32)])   # (the last: just above -- three launches)
 def test_one_launch_select_without_the_window(cuda, n, d, dtype):
     """window=False, 512 < n <= 4096: every step takes the one-launch chained radix select (k_hist_all: all levels in one
     launch, workgroups meeting at in-launch barriers, the last arrival resolving a level for all of them; the level-0 counts
