@@ -146,3 +146,42 @@ def test_fused_call_takes_the_panel_kernel_and_stays_exact(cuda):
         T = T + 1e-3 * phi
     assert hits >= 2
     assert not math.isnan(eng.h2.item())
+
+
+@pytest.mark.parametrize("n,d,dtype,sym", [(2048, 256, torch.float32, True), (2048, 256, torch.float32, False),
+                                           (1024, 2001, torch.float32, True), (2048, 256, torch.bfloat16, True),
+                                           (1536, 600, torch.bfloat16, False)])
+def test_panel_kernels_are_deterministic_under_memory_pressure(cuda, n, d, dtype, sym):
+    """The panel kernels stream their operand through inline-asm loads with hand-counted s_waitcnt vmcnt: a wait that is
+    one operation too loose reads a register before its load has landed -- only sometimes, depending on timing.  So the
+    same launch is repeated while a second stream hammers HBM and the L2 with copies (latencies move around), and every
+    repetition must reproduce the first image bit for bit, which itself matches fp64."""
+    T, G = _inputs(n, d, cuda, dtype, seed=11)
+    eng = SvgdEngine(n, d, device=cuda, x3=True, dtype=dtype, small=False)
+    st = eng.stages
+    Td = T.to(dtype)
+    st.rownorms(Td, n, d, eng.rownorm)
+    st.x3_prepare(Td, G.to(dtype), n, d, eng.planes)
+
+    def run():
+        eng.dist.fill_(float("nan"))
+        st.distance_block(Td, eng.rownorm, n, d, 0, n, eng.dist, eng.ld_dist, symmetric=sym, planes=eng.planes,
+                          kernel=_lib.STAGE_PANEL)
+
+    run()
+    torch.cuda.synchronize()
+    first = eng.dist.clone()
+    M = untile_distances(first, n, n, upper=sym)
+    ref = _fp64_dist(T)
+    assert (M.double() - ref).abs().max().item() <= (4e-6 if dtype == torch.float32 else 2e-5) * ref.abs().max().item()
+    side = torch.cuda.Stream(device=cuda)
+    a = torch.empty(64 << 20, dtype=torch.float32, device=cuda)      # 256 MB each: beyond the caches
+    b = torch.empty_like(a)
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 4):
+                b.copy_(a)
+        run()
+        torch.cuda.synchronize()
+        same = (eng.dist == first) | (eng.dist.isnan() & first.isnan())
+        assert bool(same.all()), "repetition %d differs in %d entries" % (rep, int((~same).sum()))

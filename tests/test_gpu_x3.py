@@ -218,3 +218,28 @@ def test_bf16_sampler_step(cuda):
     # first Adagrad step is lr * sign(phi) except where |phi| is tiny: compare where the oracle is not near zero
     big = np.abs(ref["phi_clipped"]) > 1e-3 * np.abs(ref["phi_clipped"]).max()
     assert np.abs(step - ref_step)[big].max() <= 1e-3   # lr = 1e-2: a tenth of a step, only where bf16 K rounding flips tiny phi
+
+
+@pytest.mark.parametrize("n,d,dtype", [(4096, 256, torch.float32), (2048, 600, torch.float32), (4096, 128, torch.bfloat16)])
+def test_fused_step_is_deterministic_under_memory_pressure(cuda, n, d, dtype):
+    """k_phi_x3fs keeps D and V loads in flight across loop iterations with hand-counted s_waitcnt vmcnt (inline asm): a
+    wait one operation too loose would feed a stale tile only sometimes.  The same fused step is repeated while a second
+    stream hammers HBM and the L2; phi, the bandwidth and |phi|^2 must come out bit-identical every time (whichever way the
+    median was found: the first calls take the radix select, the later ones the window)."""
+    g = torch.Generator(device="cpu").manual_seed(n + d)
+    T = torch.randn(n, d, generator=g).to(cuda).to(dtype)
+    G = torch.randn(n, d, generator=g).to(cuda).to(dtype)
+    eng = SvgdEngine(n, d, device=cuda, dtype=dtype, small=False)
+    first = eng.compute_phi(T, G).clone()
+    h2, sq = float(eng.h2), float(eng.sqnorm)
+    side = torch.cuda.Stream(device=cuda)
+    a = torch.empty(64 << 20, dtype=torch.float32, device=cuda)
+    b = torch.empty_like(a)
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 4):
+                b.copy_(a)
+        phi = eng.compute_phi(T, G)
+        torch.cuda.synchronize()
+        assert float(eng.h2) == h2 and float(eng.sqnorm) == sq, rep
+        assert torch.equal(phi, first), "repetition %d differs in %d entries" % (rep, int((phi != first).sum()))
