@@ -504,9 +504,12 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
   if (level0_only) return false;                                   // the caller wants the level-0 histogram from the epilogue
   if ((n & 127) || (n_local & 127) || (row0 & 127)) return false;
   // (np * ntk > 16: the panel does not fit 128 KB of LDS -> k_distance_panel_deep walks K in chunks)
-  // below ~16 strips per wave the panel loads and the ragged tail outweigh the overlap (and the launch fits one
-  // round of the tile kernel anyway)
-  return any_size || (n_local / 128) * (n / 32) >= 256 * 8 * 8;
+  // Small blocks: the launch has a floor of ~20 us (one 157 KB workgroup per CU, a panel load, a barrier) where the per-tile
+  // kernel needs 14.  Measured on symmetric blocks (scratch/dist_small_ab.py; tiles vs panel, us): n = 8192: d = 40 39 / 36,
+  // d = 128 54 / 42, d = 256 88 / 58; n = 4096: d = 128 24 / 24 (bf16 17 / 21), d = 256 36 / 29, d = 1000 100 / 67;
+  // n = 2048, d = 2001: 86 / 85.  So: 16384 strips (eight per wave) whatever K, a quarter of that when K is a full panel.
+  const int64_t strips = (n_local / 128) * (n / 32);
+  return any_size || strips >= 256 * 8 * 8 || (strips >= 256 * 8 * 2 && np * ntk >= 16);
 }
 
 int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
