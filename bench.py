@@ -512,7 +512,8 @@ def main():
         stored = tiles * 128 * 128 * 4.0 if n % 128 == 0 and nl % 128 == 0 else None
         dflop = 2.0 * nl * n * d * (0.5 if world == 1 else 1.0)
         out["distance_pass"] = {
-            "kernel": ("k_distance_x3 (one 128 x 128 tile per workgroup)" if not ((nl // 128) * (n // 32) >= 16384 and n % 128 == 0 and nl % 128 == 0)
+            "kernel": ("k_distance_x3 (one 128 x 128 tile per workgroup)" if not (n % 128 == 0 and nl % 128 == 0 and ((nl // 128) * (n // 32) >= 16384 or
+                       ((nl // 128) * (n // 32) >= 4096 and (1 if wl.get("bf16") else 2) * ((d + 31) // 32) >= 16)))   # stein_dpanel_ok
                        else "k_distance_panel (operand panel in LDS, strips streamed from L2)" if d <= (512 if wl.get("bf16") else 256)
                        else "k_distance_panel_deep (the panel in LDS a chunk of K at a time, strips streamed from L2)"),
             "ms_per_launch": d_ms, "bound": "hbm",
