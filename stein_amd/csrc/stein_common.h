@@ -558,3 +558,77 @@ int stein_small_phi(const float* theta, const float* score, int64_t n, int64_t d
                     double* sqpart /* one partial |phi|^2 per workgroup, *nparts of them (<= ceil(d / 32)) */,
                     float* K_out, float* dK_out, int* nparts /* 0: a single workgroup wrote *sqnorm_out itself */,
                     double* sqnorm_out, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// fused-call prologue (k_prologue, steinhip.hip; for bf16 inputs a slice of k_split's grid, stein_x3.hip): k_sel_init + the window set-up + zeroing of the histograms and of the "below" slots
+// (gt of gn threads share the zeroing; thread 0 sets the states up)
+__device__ __forceinline__ void median_init_body(int gt, int gn, SelState* st, SpecState* sp, u64 total,
+                                                 u64* __restrict__ hist, u64* __restrict__ slots, int allow_window = 1) {
+  for (int i = gt; i < STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS; i += gn) hist[i] = 0ull;
+  for (int i = gt; i < (int)SPEC_SLOTS * 8; i += gn) slots[i] = 0ull;
+  if (gt) return;
+  {
+    const u32 even = (total & 1ull) ? 0u : 1u;
+    st->rank[0] = even ? total / 2 - 1 : total / 2;
+    st->rank[1] = total / 2;
+    st->prefix[0] = st->prefix[1] = 0u;
+    st->diverged = 0u;
+    st->even = even;
+    st->median = st->h2 = st->lo = st->hi = 0.f;
+  }
+  // a window is granted only among the keys of positive finite floats, [0x80000000, 0xff000000): the distance epilogue
+  // tests raw bit patterns (a median <= 0 means coincident particles: h2 = 0, nothing to speed up)
+  if (allow_window && (sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) && sp->halfwidth <= SPEC_HW_MAX &&
+      sp->center >= 0x80000000u + sp->halfwidth && sp->center < 0xff000000u - sp->halfwidth) {
+    sp->lo_key = sp->center - sp->halfwidth;
+    sp->width = 2u * sp->halfwidth;
+  } else {
+    sp->lo_key = 0xffffffffu;   // no window: nothing is inside, everything is "below" (and ignored)
+    sp->width = 0u;
+  }
+  sp->count = 0u; sp->overflow = 0u; sp->hit = 0u;
+  sp->skip_l0 = sp->width == 0u ? 1u : 0u;   // no window: the distance epilogue takes the level-0 histogram itself
+  sp->reserved = 0ull; sp->total = total;
+}
+
+
+// What the fused call's first launch sets up besides the split planes: the row norms (one wave per row, the rows dealt
+// round-robin over the waves of the launch's `nb` workgroups) and, shared by all of its threads, everything the later kernels
+// expect to find zeroed or set up: the median state (median_init_body), the column maxima of the scales, the FuseState
+// tickets and -- bf16 inputs -- the neutral operand scales.
+struct PrologueArgs {
+  int n, d;
+  float* r;
+  SelState* st; SpecState* sp; FuseState* fs;
+  u64 total;
+  u64* hist; u64* slots;
+  u32* cmax; int ncmax;
+  int allow_window;
+  float* neutral_sc; int dc;
+};
+constexpr int PRO_INIT_BLOCKS = 16;   // (k_prologue's grid: one workgroup per four rows + these; any grid works)
+__device__ __forceinline__ float prologue_elem(const float* p) { return *p; }
+__device__ __forceinline__ float prologue_elem(const unsigned short* p) { return __uint_as_float((u32)*p << 16); }   // bf16 bits
+template <typename TIN>
+__device__ __forceinline__ void prologue_body(const TIN* __restrict__ T, const PrologueArgs& a, int b, int nb) {
+  const int gt = b * 256 + (int)threadIdx.x, gn = nb * 256;
+  for (int i = gt; i < a.ncmax; i += gn) a.cmax[i] = 0u;
+  if (a.neutral_sc) {   // bf16 inputs: every operand scale is 1 (what k_make_scales(enable = 0) writes), no launch for it
+    for (int i = gt; i < 4 * a.dc; i += gn) a.neutral_sc[i] = 1.f;
+    if (gt == 0) { a.neutral_sc[4 * a.dc] = 1.f; a.neutral_sc[4 * a.dc + 1] = 2.f; a.neutral_sc[4 * a.dc + 2] = 1.f; }
+  }
+  if (gt < 16) reinterpret_cast<u32*>(a.fs)[gt] = 0u;
+  median_init_body(gt, gn, a.st, a.sp, a.total, a.hist, a.slots, a.allow_window);
+  const int lane = threadIdx.x & 63;
+  for (int row = gt >> 6; row < a.n; row += gn >> 6) {
+    const TIN* rp = T + (size_t)row * a.d;
+    float s = 0.f;
+    for (int k = lane; k < a.d; k += 64) {
+      const float x = prologue_elem(rp + k);
+      s = fmaf(x, x, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) a.r[row] = s;
+  }
+}

@@ -203,11 +203,19 @@ __device__ __forceinline__ float load_as_f32(const u16* p) { return __uint_as_fl
 // transposed one (both powers of two; 1 unless KIND 2).
 // blockIdx.z = 0: theta (row-major image R and transposed image Tt0), 1: score (transposed image Tt1 only; the grid is
 // sized for theta's padded extents, blocks outside the score's exit at once)
-template <typename TIN, int KIND>
+// PRO (bf16 inputs in the fused call): the grid has one more z slice, whose workgroups do the fused call's prologue
+// (prologue_body, stein_common.h: row norms, median state, tickets, neutral scales) -- bf16 planes need no scales, so
+// nothing here waits for it, and the step is one launch shorter.  The split slices then must not READ the scales (the
+// prologue slice writes them in the same launch): they are 1 by definition for KIND 1.
+template <typename TIN, int KIND, bool PRO = false>
 __global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
                                                u16* __restrict__ R0, long r_rows, int dk, u16* __restrict__ Tt0,
                                                u16* __restrict__ Tt1, int dc, long nk, const float* __restrict__ sc,
-                                               int zbase) {
+                                               int zbase, PrologueArgs pro) {
+  if (PRO && blockIdx.z == gridDim.z - 1) {
+    prologue_body<TIN>(X0, pro, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    return;
+  }
   const bool score = blockIdx.z + zbase != 0;
   if (score && ((int)blockIdx.x * 64 >= dc || (long)blockIdx.y * 64 >= nk)) return;
   const TIN* __restrict__ X = score ? X1 : X0;
@@ -220,10 +228,10 @@ __global__ __launch_bounds__(256) void k_split(const TIN* __restrict__ X0, const
   const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
   const int lr = t >> 4, lc = (t & 15) * 4;
   const long ntk_r = dk >> 5, ntk_t = nk >> 5;
-  const float sa = R ? *sc_all : 1.f;
+  const float sa = (R && !PRO) ? *sc_all : 1.f;
   float scq[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) scq[q] = (Tt && col0 + lc + q < dc) ? sc_col[col0 + lc + q] : 1.f;
+  for (int q = 0; q < 4; ++q) scq[q] = (!PRO && Tt && col0 + lc + q < dc) ? sc_col[col0 + lc + q] : 1.f;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int row = row0 + lr + 16 * p, col = col0 + lc;
@@ -850,21 +858,28 @@ int stein_x3_kind(int dtype) { return split_kind(dtype); }
 
 template <typename TIN, int KIND>
 static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score, int64_t n, int64_t d,
-                         const SteinLayout& L, u16* T3, u16* Tt3, u16* Gt3, const float* sc) {
+                         const SteinLayout& L, u16* T3, u16* Tt3, u16* Gt3, const float* sc, const PrologueArgs* pro = nullptr) {
   // grid.z walks [theta, score]; a NULL matrix is left out (its planes keep their contents)
   const unsigned nz = (theta ? 1u : 0u) + (score ? 1u : 0u);
   const int zbase = theta ? 0 : 1;
   const int64_t rows = L.x3_rows > L.x3_nk ? L.x3_rows : L.x3_nk;   // particle extent to cover (both multiples of 32)
   const int64_t cols = L.x3_dk > L.x3_dc ? L.x3_dk : L.x3_dc;      // parameter extent
+  if (KIND == 1 && pro && theta) {   // + the prologue slice (fused call, bf16)
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), nz + 1u);
+    hipLaunchKernelGGL((k_split<TIN, KIND, true>), grid, dim3(256), 0, stream, theta, score, (int)n, (int)d, T3,
+                       (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc, zbase, *pro);
+    return;
+  }
   const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), nz);
-  hipLaunchKernelGGL((k_split<TIN, KIND>), grid, dim3(256), 0, stream, theta, score, (int)n, (int)d, T3,
-                     (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc, zbase);
+  hipLaunchKernelGGL((k_split<TIN, KIND, false>), grid, dim3(256), 0, stream, theta, score, (int)n, (int)d, T3,
+                     (long)L.x3_rows, (int)L.x3_dk, Tt3, Gt3, (int)L.x3_dc, (long)L.x3_nk, sc, zbase, PrologueArgs{});
 }
 
 // fuse_done != NULL (fused call): the caller has zeroed the column maxima and the ticket, both matrices are given, and
 // the column-maxima kernel's last workgroup writes the scales itself
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
-                   const SteinLayout& L, char* planes, hipStream_t stream, u32* fuse_done, bool scales_written) {
+                   const SteinLayout& L, char* planes, hipStream_t stream, u32* fuse_done, bool scales_written,
+                   const PrologueArgs* prologue) {
   u16* T3 = reinterpret_cast<u16*>(planes + L.x3_t3);
   u16* Tt3 = reinterpret_cast<u16*>(planes + L.x3_tt3);
   u16* Gt3 = reinterpret_cast<u16*>(planes + L.x3_gt3);
@@ -892,7 +907,7 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
                        kind == 2 ? 1 : 0);
     LAUNCH_CHECK("k_make_scales");
   }
-  if (kind == 1) launch_split<u16, 1>(stream, (const u16*)theta_all, (const u16*)score_all, n, d, L, T3, Tt3, Gt3, sc);
+  if (kind == 1) launch_split<u16, 1>(stream, (const u16*)theta_all, (const u16*)score_all, n, d, L, T3, Tt3, Gt3, sc, prologue);
   else launch_split<float, 2>(stream, (const float*)theta_all, (const float*)score_all, n, d, L, T3, Tt3, Gt3, sc);
   LAUNCH_CHECK("k_split");
   return STEIN_OK;

@@ -469,76 +469,16 @@ __global__ __launch_bounds__(64) void k_resolve(const u64* __restrict__ hist, in
 
 // ------------------------------------------------------------------------------------------------
 // speculative median window (SpecState in stein_common.h): begin / select / update, one launch each per step
-// ------------------------------------------------------------------------------------------------
-// fused-call prologue: k_sel_init + the window set-up + zeroing of the histograms and of the "below" slots
-// (gt of gn threads share the zeroing; thread 0 sets the states up)
-__device__ __forceinline__ void median_init_body(int gt, int gn, SelState* st, SpecState* sp, u64 total,
-                                                 u64* __restrict__ hist, u64* __restrict__ slots, int allow_window = 1) {
-  for (int i = gt; i < STEIN_HIST_LEVELS * 2 * STEIN_HIST_BINS; i += gn) hist[i] = 0ull;
-  for (int i = gt; i < (int)SPEC_SLOTS * 8; i += gn) slots[i] = 0ull;
-  if (gt) return;
-  {
-    const u32 even = (total & 1ull) ? 0u : 1u;
-    st->rank[0] = even ? total / 2 - 1 : total / 2;
-    st->rank[1] = total / 2;
-    st->prefix[0] = st->prefix[1] = 0u;
-    st->diverged = 0u;
-    st->even = even;
-    st->median = st->h2 = st->lo = st->hi = 0.f;
-  }
-  // a window is granted only among the keys of positive finite floats, [0x80000000, 0xff000000): the distance epilogue
-  // tests raw bit patterns (a median <= 0 means coincident particles: h2 = 0, nothing to speed up)
-  if (allow_window && (sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) && sp->halfwidth <= SPEC_HW_MAX &&
-      sp->center >= 0x80000000u + sp->halfwidth && sp->center < 0xff000000u - sp->halfwidth) {
-    sp->lo_key = sp->center - sp->halfwidth;
-    sp->width = 2u * sp->halfwidth;
-  } else {
-    sp->lo_key = 0xffffffffu;   // no window: nothing is inside, everything is "below" (and ignored)
-    sp->width = 0u;
-  }
-  sp->count = 0u; sp->overflow = 0u; sp->hit = 0u;
-  sp->skip_l0 = sp->width == 0u ? 1u : 0u;   // no window: the distance epilogue takes the level-0 histogram itself
-  sp->reserved = 0ull; sp->total = total;
-}
-
 __global__ __launch_bounds__(256) void k_median_init(SelState* st, SpecState* sp, u64 total, u64* __restrict__ hist,
                                                      u64* __restrict__ slots) {
   median_init_body(blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, st, sp, total, hist, slots);
 }
 
-// First kernel of the fused call: the row norms (workgroups [0, row_blocks), one wave per row as in k_rownorms) and, in
-// the PRO_INIT_BLOCKS workgroups behind them, everything the later kernels expect to find zeroed or set up: the
-// median state (median_init_body), the column maxima of the scales and the FuseState tickets.
-constexpr int PRO_INIT_BLOCKS = 16;
+// First kernel of the fused call (fp32 inputs; bf16 inputs: the same work rides in k_split's launch, stein_x3.hip): the row
+// norms and everything the later kernels expect to find zeroed or set up (prologue_body, stein_common.h).
 template <typename TIN>
-__global__ __launch_bounds__(256) void k_prologue(const TIN* __restrict__ T, int n, int d, float* __restrict__ r,
-                                                  int row_blocks, SelState* st, SpecState* sp, FuseState* fs, u64 total,
-                                                  u64* __restrict__ hist, u64* __restrict__ slots,
-                                                  u32* __restrict__ cmax, int ncmax, int allow_window,
-                                                  float* __restrict__ neutral_sc, int dc) {
-  if ((int)blockIdx.x >= row_blocks) {
-    const int gt = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x, gn = PRO_INIT_BLOCKS * 256;
-    for (int i = gt; i < ncmax; i += gn) cmax[i] = 0u;
-    if (neutral_sc) {   // bf16 inputs: every operand scale is 1 (what k_make_scales(enable = 0) writes), no launch for it
-      for (int i = gt; i < 4 * dc; i += gn) neutral_sc[i] = 1.f;
-      if (gt == 0) { neutral_sc[4 * dc] = 1.f; neutral_sc[4 * dc + 1] = 2.f; neutral_sc[4 * dc + 2] = 1.f; }
-    }
-    if (gt < 16) reinterpret_cast<u32*>(fs)[gt] = 0u;
-    median_init_body(gt, gn, st, sp, total, hist, slots, allow_window);
-    return;
-  }
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (wave >= n) return;
-  const TIN* row = T + (size_t)wave * d;
-  float s = 0.f;
-  for (int k = lane; k < d; k += 64) {
-    const float x = elem_f32(row + k);
-    s = fmaf(x, x, s);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) r[wave] = s;
+__global__ __launch_bounds__(256) void k_prologue(const TIN* __restrict__ T, PrologueArgs a) {
+  prologue_body<TIN>(T, a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* sp);   // below
@@ -1790,22 +1730,28 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
       cmax = (u32*)((float*)((char*)planes + L.x3_sc) + 4 * L.x3_dc + 4);
       ncmax = (int)(2 * L.x3_dc);
     }
-    const int row_blocks = (int)((n + 3) / 4);
-    const int allow_window = (flags & STEIN_FLAG_NO_WINDOW) ? 0 : 1;
-    const dim3 grid((unsigned)(row_blocks + PRO_INIT_BLOCKS));
-    if (dtype == STEIN_BF16)
-      hipLaunchKernelGGL(k_prologue<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)theta_all, (int)n,
-                         (int)d, r, row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax,
-                         allow_window, planes ? (float*)((char*)planes + L.x3_sc) : (float*)nullptr, (int)L.x3_dc);
-    else
-      hipLaunchKernelGGL(k_prologue<float>, grid, dim3(256), 0, s, (const float*)theta_all, (int)n, (int)d, r,
-                         row_blocks, (SelState*)sel, spec, fuse, (u64)(n * n), (u64*)hist, spec_buf, cmax, ncmax, allow_window,
-                         (float*)nullptr, 0);
-    LAUNCH_CHECK("k_prologue");
+    PrologueArgs pa;
+    pa.n = (int)n; pa.d = (int)d; pa.r = r; pa.st = (SelState*)sel; pa.sp = spec; pa.fs = fuse; pa.total = (u64)(n * n);
+    pa.hist = (u64*)hist; pa.slots = spec_buf; pa.cmax = cmax; pa.ncmax = ncmax;
+    pa.allow_window = (flags & STEIN_FLAG_NO_WINDOW) ? 0 : 1;
+    pa.neutral_sc = (dtype == STEIN_BF16 && planes) ? (float*)((char*)planes + L.x3_sc) : (float*)nullptr;
+    pa.dc = (int)L.x3_dc;
+    if (dtype == STEIN_BF16 && planes) {
+      // bf16 inputs need no scales, so the split does not depend on the prologue: both ride in ONE launch (k_split's grid
+      // gets a third slice that does the prologue's work) -- one launch less on the latency-bound sizes this dtype is for
+      if ((rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax, true, &pa))) return rc;
+    } else {
+      const int row_blocks = (int)((n + 3) / 4);
+      const dim3 grid((unsigned)(row_blocks + PRO_INIT_BLOCKS));
+      if (dtype == STEIN_BF16)
+        hipLaunchKernelGGL(k_prologue<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)theta_all, pa);
+      else
+        hipLaunchKernelGGL(k_prologue<float>, grid, dim3(256), 0, s, (const float*)theta_all, pa);
+      LAUNCH_CHECK("k_prologue");
+      if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax, false, nullptr)))
+        return rc;
+    }
   }
-  if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax,
-                                     dtype == STEIN_BF16 /* the prologue has written the neutral scales */)))
-    return rc;
   STEIN_TSTAMP(STEIN_T_DISTANCE);
   if ((rc = distance_block_impl(theta_all, r, n, d, row0, n_local, dtype, D, L.ld_dist, hist, planes, sf, stream, spec,
                                 spec_buf)))
