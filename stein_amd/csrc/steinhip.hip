@@ -1719,9 +1719,11 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     STEIN_TSTAMP(STEIN_T_NSTAGES);
     return STEIN_OK;
   }
-  // The prologue carries the row norms and all set-up; two kernels let their last workgroup do what a one-workgroup
-  // follow-up launch would (FuseState tickets): twelve launches where the separate stages take sixteen (nine for
-  // n <= SOLO_MAX_N, where k_spec_select also covers the radix select).
+  // The prologue carries the row norms and all set-up; kernels let their last workgroup do what a one-workgroup follow-up
+  // launch would (FuseState tickets: scales, final resolve, |phi|^2 sum); the chained radix select is one launch for
+  // n <= HIST_ALL_MAX_N and none for n <= SOLO_MAX_N (k_spec_select covers it); bf16 inputs need no scales, so their
+  // prologue rides in the split's launch.  fp32 inputs: k_prologue, k_colmax, k_split, distance, k_spec_select, select
+  // (0 / 1 / 3 launches), contraction, k_phi_finish (+ k_sum_partials beyond 512 workgroups); bf16 at C2's size: six.
   FuseState* fuse = (FuseState*)((char*)sel + sizeof(SelState) + sizeof(SpecState));
   {
     u32* cmax = nullptr;
