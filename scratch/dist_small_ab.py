@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stein_amd import _lib
 from stein_amd.engine import SvgdEngine
 dev = "cuda"
-for n, d, dtype in ((1024, 128, torch.float32), (2048, 128, torch.float32), (4096, 128, torch.bfloat16), (4096, 128, torch.float32),
+for n, d, dtype in ((4096, 512, torch.bfloat16), (4096, 1024, torch.bfloat16), (8192, 128, torch.bfloat16), (8192, 512, torch.bfloat16), (4096, 320, torch.float32), (4096, 2001, torch.float32), (1024, 128, torch.float32), (2048, 128, torch.float32), (4096, 128, torch.bfloat16), (4096, 128, torch.float32),
                     (4096, 256, torch.float32), (8192, 128, torch.float32), (8192, 256, torch.float32), (8192, 40, torch.float32),
                     (4096, 1000, torch.float32), (2048, 2001, torch.float32)):
     eng = SvgdEngine(n, d, device=dev, x3=True, dtype=dtype, small=False)
