@@ -462,9 +462,26 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FS_STAGE];
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int cb = logical % cblocks;
-  const int tile_m = (logical / cblocks) % tiles_m;
-  const int z = logical / (cblocks * tiles_m);
+  // Which (row tile, column block) a workgroup takes.  An XCD runs 32 consecutive logical ids at a time (one workgroup per
+  // CU) and its 4 MB L2 is what they share: the workgroups of one row tile read the same D tiles, the workgroups of one
+  // column block the same V fragments.  With R row tiles x C column blocks resident, a launch pulls D (16 / C) times and V
+  // (tiles_m / R) times from beyond the L2.  Up to 4 column blocks (d <= 256) all of a row tile's workgroups are neighbours
+  // anyway; a wide [G | theta] (C4: 16 column blocks) dealt that way made an XCD 2 row tiles x 16 blocks -- V, 134 MB, came
+  // in 32 times (4.8 GB of HBM traffic per launch by the counters); 8 row tiles x 4 blocks asks for both four to eight times.
+  int cb, tile_m;
+  const int plane = cblocks * tiles_m, l2 = logical % plane;
+  const int z = logical / plane;
+#ifndef STEIN_PHI_ROWMAJOR_MAP   // (diagnostic builds: the plain order everywhere, for same-box A/B runs)
+  if (cblocks > 4 && (cblocks & 3) == 0 && (tiles_m & 7) == 0) {
+    const int sb = l2 >> 5, in = l2 & 31, cgroups = cblocks >> 2;
+    cb = (sb % cgroups) * 4 + (in & 3);
+    tile_m = (sb / cgroups) * 8 + (in >> 2);
+  } else
+#endif
+  {
+    cb = l2 % cblocks;
+    tile_m = l2 / cblocks;
+  }
   const int i0 = tile_m * Geo::ROWS;
   const int jbeg = z * jchunk;
   const int jend = min(n, jbeg + jchunk);
