@@ -16,13 +16,17 @@ steps each and reports them under `other_configs` (they are parity-test cases, n
 
 value = n * K / (max-over-ranks wall time of the K timed steps), bracketed by barrier + synchronize.
 
-roofline (the K.[G|theta] contraction kernel, k_phi_x3fs; k_phi_partial with STEIN_X3=0): duration from HIP events
+roofline (the K.[G|theta] contraction kernel, k_phi_x3fs; k_phi_partial with x3=False): duration from HIP events
 recorded around each of its launches on the launching stream inside the timed region (by the library at one rank:
-STEIN_FLAG_TIMING).  `achieved` = the 16-bit MFMA flops the kernel EXECUTES (3 products per fp32 operand pair x the
-algorithmic 4*n_local*n*d: 2*n^2*d for K.G plus 2*n^2*d for K.theta) per second, `peak` = 2.5 PFLOP/s
-dense fp16/bf16 MFMA (MI355X_MICROARCH.md): `frac` is the fraction of the pipe the kernel actually runs on and is
-<= 1.  The algorithmic fp32 flops against the fp32-input MFMA peak (157.3 TFLOP/s, what an fp32 GEMM could reach at
-most) are reported beside it as `fp32_equivalent_*`; the strict fp32-input MFMA kernels are timed under `fp32_path`.
+STEIN_FLAG_TIMING).  `achieved` = the ALGORITHMIC flops per launch of SURVEY 8(d) (4*n_local*n*d: 2*n^2*d for K.G plus
+2*n^2*d for K.theta) per second, `peak` = 2.5 PFLOP/s dense fp16/bf16 MFMA (MI355X_MICROARCH.md: the pipe the kernel runs
+on), `frac` = achieved / peak (= `frac_algorithmic`).  The split path executes 3 fp16 products per fp32 operand pair:
+`frac_executed` (3x) is the utilisation of that pipe, `mfma_busy_frac` the counter's reading of the same, and
+`frac_vs_fp32_mfma_peak` the algorithmic flops against the 157.3 TFLOP/s fp32-input MFMA peak (what an fp32 GEMM could
+reach at most); the strict fp32-input MFMA kernels are timed under `fp32_path`.
+
+wall_minus_events_ms (every timed entry): wall time per step minus the GPU time the HIP events of the same steps bracket;
+`host_stall_suspected` when the gap exceeds max(0.05 ms, 25 %).  A stalled headline loop is timed once more (`retimed`).
 
 window: the headline step uses the speculative median window (exact, stein_common.h); `window` reports how many of the
 timed steps it delivered the median, and `miss_path` times the same steps with the window disabled (every step pays the
@@ -91,6 +95,17 @@ class StageClock:
             for (la, ea), (_, eb) in zip(marks[:-1], marks[1:]):
                 acc.setdefault(la, []).append(ea.elapsed_time(eb))
         return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def gap_fields(wall_ms, events_ms):
+    """Wall time per step against the GPU time the HIP events of the same steps bracket (the library's stage events plus the
+    apply kernel's pair; they do not cover the host's time BETWEEN two steps): a gap means the host, not the GPU, set the
+    pace -- a stall that would otherwise hide inside ms_per_step."""
+    if events_ms is None:
+        return {"events_ms": None, "wall_minus_events_ms": None, "host_stall_suspected": None}
+    gap = wall_ms - events_ms
+    return {"events_ms": round(events_ms, 4), "wall_minus_events_ms": round(gap, 4),
+            "host_stall_suspected": bool(gap > max(0.05, 0.25 * events_ms))}
 
 
 def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
@@ -200,6 +215,8 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
         stages = clock.summary() if clock_stages else {}
         if "end" in stages:            # interval end -> apply_end is the optimizer apply kernel
             stages["apply"] = stages.pop("end")
+    # the GPU time the stage events account for, per step (one rank: every stage of the fused call + the apply kernel)
+    events_ms = float(sum(stages.values())) if (world == 1 and clock_stages and stages) else None
     finite = bool(torch.isfinite(theta).all().item())
     # parity on sampled rows: one more call, untimed, no apply (theta and phi then belong together)
     cur = feed()
@@ -211,7 +228,7 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
         T_all, G_all = cur.float(), G.float()
     relerr, nrows = parity_sample(torch, T_all, G_all, phi, row0, float(eng.h2.item()))
     crosscheck = None
-    return dict(comm=eng.comm, comm_note=comm_note, comm_crosscheck=crosscheck, n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, finite=finite, split=eng.split,
+    return dict(comm=eng.comm, comm_note=comm_note, comm_crosscheck=crosscheck, n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, events_ms=events_ms, finite=finite, split=eng.split,
                 ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3, parity_relerr=relerr, parity_rows=nrows,
                 window=dict(timed_steps=stats1[0] - stats0[0], hits=stats1[1] - stats0[1]) if has_window else None)
 
@@ -276,13 +293,20 @@ def train_on_batch_entry(torch, device, steps, warmup):
         s.train_on_batch(feed)
     torch.cuda.synchronize(device)
     st0 = s.engine.window_stats()
+    pairs = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         s.train_on_batch(feed)
+        e1.record()
+        pairs.append((e0, e1))
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     st1 = s.engine.window_stats()
-    return {"what": "SteinSampler.train_on_batch at the C3 shape (n=16384, d=256): logistic-regression score recomputed from theta "
+    ev_ms = sum(a.elapsed_time(b) for a, b in pairs) / steps     # GPU time bracketed per iteration (not between iterations)
+    return {**gap_fields(dt / steps * 1e3, ev_ms),
+            "what": "SteinSampler.train_on_batch at the C3 shape (n=16384, d=256): logistic-regression score recomputed from theta "
                     "on the device every iteration (GlmScore, minibatch 50), fused SVGD step, Adagrad apply",
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": n * steps / dt, "unit": "particle-updates/s",
             "window": {"timed_steps": st1[0] - st0[0], "hits": st1[1] - st0[1]},
@@ -402,8 +426,9 @@ def main():
                          "library's own RCCL communicator); the other way is run once afterwards as a cross-check")
     ap.add_argument("--no-train-on-batch", action="store_true", help="skip the SteinSampler.train_on_batch entry (one GPU)")
     ap.add_argument("--secondary", default="c5", help="also time this workload briefly (extra key); 'none' to skip")
-    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief C1 / C2 / C4 timings (one GPU)")
+    ap.add_argument("--fp32-mfma", action="store_true", help="headline on the strict fp32-input MFMA kernels (x3=False)")
     ap.add_argument("--no-variants", action="store_true", help="skip the miss-path and fp32-path timings (one GPU)")
     args = ap.parse_args()
 
@@ -440,8 +465,18 @@ def main():
     if args.n or args.d:
         wl["n"], wl["d"] = args.n or wl["n"], args.d or wl["d"]
         wl["name"] = "custom n=%d d=%d fp32" % (wl["n"], wl["d"])
-    env_x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
-    res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm)
+    env_x3 = not args.fp32_mfma
+    hx3 = False if args.fp32_mfma else None
+    res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3)
+    retimed = None
+    if world == 1 and gap_fields(res["elapsed"] / args.steps * 1e3, res["events_ms"])["host_stall_suspected"]:
+        # the host, not the GPU, set the pace of the timed loop (a stalled launch thread on a shared box): say so and time
+        # the same K steps once more; the line reports the second run and keeps the first one's numbers beside it
+        retimed = {"why": "wall time per step exceeded the event-bracketed GPU time by more than max(0.05 ms, 25 %): host stall",
+                   "first_run_ms_per_step": res["elapsed"] / args.steps * 1e3, "first_run_events_ms": res["events_ms"]}
+        del res
+        torch.cuda.empty_cache()
+        res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3)
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
     value = n * args.steps / res["elapsed"]
@@ -451,18 +486,25 @@ def main():
     alg = flops / (k_ms * 1e-3) if k_ms else None
     traffic, traffic_src, mfma_busy, pmc_ent = pmc_traffic(args.workload, res["x3"]) if world == 1 else (None, None, None, {})
     if res["x3"]:
+        # achieved = ALGORITHMIC flops per launch (4 n_local n d) / the kernel's mean duration, against the peak
+        # of the pipe the kernel runs on (dense fp16/bf16 MFMA).  The split path executes `nprod` 16-bit products per fp32
+        # operand pair, so the pipe utilisation is nprod x that; it is reported beside it, never as `frac`.
         roof = {
             "kernel": "k_phi_x3fs (exp + split-precision MFMA K.[G|theta] contraction, %d 16-bit products per operand pair)" % nprod,
-            "bound": "mfma", "achieved": nprod * alg / 1e12 if alg else None, "peak": PEAK_16BIT_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": nprod * alg / PEAK_16BIT_MFMA if alg else None,
-            "frac_executed": nprod * alg / PEAK_16BIT_MFMA if alg else None,
+            "bound": "mfma", "achieved": alg / 1e12 if alg else None, "peak": PEAK_16BIT_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": alg / PEAK_16BIT_MFMA if alg else None,
             "frac_algorithmic": alg / PEAK_16BIT_MFMA if alg else None,
+            "frac_executed": nprod * alg / PEAK_16BIT_MFMA if alg else None,
+            "executed_tflops": nprod * alg / 1e12 if alg else None,
             "mfma_busy_frac": mfma_busy,
-            "note": "frac = frac_executed = EXECUTED 16-bit MFMA flops (%d products x the algorithmic 4 n_local n d) / mean kernel "
-                    "time / the dense fp16/bf16 MFMA peak: the fraction of the pipe the kernel runs on.  frac_algorithmic = the "
-                    "algorithmic 4 n_local n d flops alone against the same peak.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
-                    "(1024 SIMDs x 2.4 GHz x kernel time) from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), "
-                    "an independent reading of frac_executed" % nprod,
+            "frac_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA if alg else None,
+            "note": "achieved / frac = frac_algorithmic = the ALGORITHMIC 4 n_local n d flops of SURVEY 8(d) / mean kernel time / the "
+                    "dense fp16/bf16 MFMA peak (the pipe the kernel runs on).  frac_executed = the 16-bit MFMA flops the kernel "
+                    "EXECUTES (%d products per fp32 operand pair x the algorithmic flops) against the same peak: the utilisation "
+                    "of that pipe.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x 2.4 GHz x kernel time) from the "
+                    "committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), an independent reading of frac_executed.  "
+                    "frac_vs_fp32_mfma_peak = the algorithmic flops against the 157.3 TFLOP/s fp32-input MFMA peak (SURVEY 7: a "
+                    "split emulation is also reported against the fp32 peak; > 1 means faster than any fp32-MFMA GEMM)" % nprod,
             "fp32_equivalent_tflops": alg / 1e12 if alg else None,
             "fp32_equivalent_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA if alg else None,
         }
@@ -471,6 +513,8 @@ def main():
             "kernel": "k_phi_partial (exp + fp32-input MFMA K.[G|theta] contraction)",
             "bound": "mfma", "achieved": alg / 1e12 if alg else None, "peak": PEAK_FP32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": alg / PEAK_FP32_MFMA if alg else None,
+            "frac_algorithmic": alg / PEAK_FP32_MFMA if alg else None,
+            "frac_executed": alg / PEAK_FP32_MFMA if alg else None,
             "note": "fp32-input MFMA kernel: algorithmic = executed flops",
         }
     roof.update({"algorithmic_flops_per_launch": flops, "executed_flops_per_launch": nprod * flops, "ms_per_launch": k_ms,
@@ -502,6 +546,8 @@ def main():
         "roofline": roof,
         "gemm_path": ({1: "bf16 inputs (1 product)", 3: "split fp16 x 2 (3 products)"}[nprod]) if res["x3"] else "fp32 mfma",
         "stage_ms": {k: round(v, 4) for k, v in res["stages"].items()},
+        **gap_fields(ms_per_step, res["events_ms"]),
+        "retimed": retimed,
         "window": res["window"],
         "full_step_tflops": 6.0 * nl * n * d / (ms_per_step * 1e-3) / 1e12,
         "finite": res["finite"],
@@ -547,6 +593,7 @@ def main():
                                     "radix-select passes over D (what a window miss costs)",
                             "steps": 10, "ms_per_step": rm["elapsed"] / 10 * 1e3,
                             "stage_ms": {k: round(v, 4) for k, v in rm["stages"].items()},
+                            **gap_fields(rm["elapsed"] / 10 * 1e3, rm["events_ms"]),
                             "parity_sample_relerr": rm["parity_relerr"]}
         del rm
         torch.cuda.empty_cache()
@@ -555,6 +602,7 @@ def main():
         out["fp32_path"] = {"what": "the same step on the fp32-input MFMA kernels (x3=False): exact k-ordered fmaf chains",
                             "steps": 5, "ms_per_step": rf["elapsed"] / 5 * 1e3,
                             "stage_ms": {k: round(v, 4) for k, v in rf["stages"].items()},
+                            **gap_fields(rf["elapsed"] / 5 * 1e3, rf["events_ms"]),
                             "contract_ms": kf, "contract_tflops": flops / (kf * 1e-3) / 1e12 if kf else None,
                             "contract_frac_of_fp32_mfma_peak": flops / (kf * 1e-3) / PEAK_FP32_MFMA if kf else None,
                             "parity_sample_relerr": rf["parity_relerr"]}
@@ -566,7 +614,8 @@ def main():
         out["tile_distance_path"] = {"what": "the same step with the distance pass on the per-tile kernel (k_distance_x3, round 2's) "
                                              "instead of the panel-resident one: same-box A/B",
                                      "steps": 10, "ms_per_step": rt["elapsed"] / 10 * 1e3,
-                                     "stage_ms": {k: round(v, 4) for k, v in rt["stages"].items()}}
+                                     "stage_ms": {k: round(v, 4) for k, v in rt["stages"].items()},
+                                     **gap_fields(rt["elapsed"] / 10 * 1e3, rt["events_ms"])}
         del rt
     if world == 1 and args.workload == "c3" and not args.no_train_on_batch:
         torch.cuda.empty_cache()
@@ -582,6 +631,9 @@ def main():
             k2 = r2["stages"].get("contract")
             f2 = 4.0 * r2["n_local"] * r2["n"] * r2["d"]
             np2 = (1 if wl2.get("bf16") else 3) if r2["x3"] else 1     # 16-bit products per operand pair (1: the fp32-input MFMA kernel)
+            # the configuration the north star's ">= 6x at 8 GPUs" refers to: its per-N value also at the top level of the line
+            out["secondary_value"] = r2["n"] * args.secondary_steps / r2["elapsed"]
+            out["secondary_config"] = "%s: n=%d d=%d, %d ranks, %d timed steps" % (args.secondary, r2["n"], r2["d"], world, args.secondary_steps)
             out["secondary"] = {
                 "workload": wl2["name"], "n": r2["n"], "d": r2["d"], "steps": args.secondary_steps,
                 "ms_per_step": r2["elapsed"] / args.secondary_steps * 1e3,
@@ -592,6 +644,7 @@ def main():
                 ("contract_frac_of_16bit_mfma_peak" if r2["x3"] else "contract_frac_of_fp32_mfma_peak"):
                     np2 * f2 / (k2 * 1e-3) / (PEAK_16BIT_MFMA if r2["x3"] else PEAK_FP32_MFMA) if k2 else None,
                 "stage_ms": {k: round(v, 4) for k, v in r2["stages"].items()}, "finite": r2["finite"],
+                **gap_fields(r2["elapsed"] / args.secondary_steps * 1e3, r2["events_ms"]),
                 "window": r2["window"], "parity_sample_relerr": r2["parity_relerr"],
             }
             del r2
@@ -608,6 +661,8 @@ def main():
                            "ms_per_step": ro["elapsed"] / 20 * 1e3, "value": ro["n"] * 20 / ro["elapsed"],
                            "unit": "particle-updates/s", "finite": ro["finite"],
                            "stage_ms": {k: round(v, 4) for k, v in rs["stages"].items()},
+                           "staged_run_ms_per_step": rs["elapsed"] / 8 * 1e3,   # the 8-step run that carried the stage events
+                           **gap_fields(rs["elapsed"] / 8 * 1e3, rs["events_ms"]),
                            "window": ro["window"], "parity_sample_relerr": ro["parity_relerr"]}
             del rs
             if not args.no_cpu_baseline:     # the NumPy oracle on the same inputs (C4: a bounded row block)
@@ -641,7 +696,7 @@ def main():
                 out["collectives"]["crosscheck_native_vs_torch"] = {"timed_out": True}
                 if rank == 0:
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)      # a hang is a failure: never exit 0 from here
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             out["collectives"]["crosscheck_native_vs_torch"] = crosscheck_comms(torch, dist, wl, device, rank, world, group)

@@ -119,7 +119,10 @@ int stein_workspace_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int
  *   h2_out               : float[1], receives bandwidth^2
  *   sqnorm_out           : double[1], receives sum(phi_local^2) (the rank-local part of |phi|_F^2)
  *   K_out / dK_out       : optional (may be NULL): [n_local][n] float / [n_local][d] float
- * Valid only when n_local == n (one rank sees every row, so the median is global).
+ * row0 / n_local: this is the SINGLE-RANK entry -- row0 must be 0 and n_local must equal n (one rank sees every row, so
+ * the median is global), anything else returns STEIN_E_BADARG.  The two arguments stay in the signature because SURVEY.md
+ * section 8(b) fixes it (a binding written against that table keeps working); a rank of a sharded run calls
+ * stein_rank_step, or the stein_rank_* segments with its own collectives between them (below).
  * The workspace carries state from one call to the next: the SELECT section keeps the median of the two previous
  * calls and, from the third call on, the distance pass counts the entries below a narrow window around the
  * extrapolated median and collects the entries inside it; when both median ranks fall inside the window an exact
@@ -355,6 +358,21 @@ int stein_score_bnn(const float* theta, int64_t n, int64_t d, int64_t n_in, int6
 /* small helpers used by the host layer */
 int stein_cast_f64_to_f32(const double* src, float* dst, int64_t count, void* stream);
 int stein_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
+
+/* ---- device error word -----------------------------------------------------------------------------
+ * The entry points are asynchronous, so a kernel that has to give up cannot return a code.  It writes NaN into what it
+ * was computing (the step's bandwidth: the reference's own failure value, compute_median.py:4-16 of identical particles)
+ * and raises a per-device word in page-locked host memory; stein_svgd_phi and stein_apply_* look at that word -- a plain
+ * host read, no synchronisation -- before they queue anything and return STEIN_E_HIP once, naming the kernel.  Today one
+ * kernel can raise it: the one-launch radix select of the fused call (512 < n <= 4096), whose level barriers are
+ * bounded although they cannot deadlock by construction.
+ * stein_take_device_error: the same check on demand (0, or STEIN_E_HIP once).
+ * Test hooks (per calling thread, no effect on results): stein_debug_hist_all_grid(blocks) launches that kernel with
+ * `blocks` workgroups instead of 512 (0 = default; any grid >= 1 gives the same median: tests/test_gpu_spec.py);
+ * stein_debug_raise_device_error raises the current device's word as a kernel would. */
+int stein_take_device_error(void);
+int stein_debug_hist_all_grid(int blocks);
+int stein_debug_raise_device_error(void);
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,7 @@ for n, d in ((2048, 256), (16384, 256)):
                                ("segments + torch collectives, radix", "0", {}, dict(group=dist.group.WORLD, force_collectives=True, comm="torch")),
                                ("segments + torch collectives, window", "1", {}, dict(group=dist.group.WORLD, force_collectives=True, comm="torch")),
                                ("staged calls, radix form (round 1)", "0", dict(mark=lambda s: None), dict(group=dist.group.WORLD, force_collectives=True, comm="torch"))):
-        os.environ["STEIN_DIST_WINDOW"] = env
-        eng = SvgdEngine(n, d, device=dev, small=False, **ekw)
+        eng = SvgdEngine(n, d, device=dev, small=False, dist_window=(env == "1") if ekw else None, **ekw)
         for _ in range(8): eng.compute_phi(T, G, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(50): eng.compute_phi(T, G, **kw)

@@ -78,6 +78,9 @@ _SIGNATURES = {
     "stein_apply_adam": [_vp, _vp, _int, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp],
     "stein_cast_f64_to_f32": [_vp, _vp, _i64, _vp],
     "stein_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "stein_take_device_error": [],
+    "stein_debug_hist_all_grid": [_int],
+    "stein_debug_raise_device_error": [],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["stein_version", "stein_last_error"])
 

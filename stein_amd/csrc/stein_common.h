@@ -136,10 +136,15 @@ static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
 // kernel; each ticket also resets itself.
 struct FuseState {
   u32 done_colmax, done_hist, done_finish;
-  u32 bar[2];      // k_hist_all: arrivals at its level barriers; the generation whose state has been published
-  u32 pub[7];      // k_hist_all: the select state the last arrival resolved (prefix[2], rank[2] as halves, diverged)
-  u32 gave_up;     // k_hist_all: a workgroup's bounded wait at a barrier ran out (the bandwidth becomes NaN)
-  u32 pad[3];
+  // k_hist_all (the chained select in one launch, steinhip.hip).  The work of a level is cut into G "virtual workgroups";
+  // whichever real workgroups are running DRAW them from draw[level], so a level completes with any number of resident
+  // workgroups and nobody ever waits for a workgroup that has not started.
+  u32 draw[3];     // next virtual workgroup of each level
+  u32 done[3];     // virtual workgroups of each level whose counts have reached the global histogram
+  u32 gen;         // levels resolved and published since the launch
+  u32 pub[4];      // the select state the resolver published: prefix[2], rank[2] (n <= 4096: the ranks fit 32 bits)
+  u32 gave_up;     // a bounded wait ran out (cannot happen by construction; the bandwidth becomes NaN and the host is told)
+  u32 pad[1];
 };
 static_assert(sizeof(FuseState) == 64, "FuseState must stay 64 bytes");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;

@@ -265,11 +265,11 @@ struct HistFinal {
 };
 __device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out);   // below
 
-// one histogram pass of a workgroup over its share of the block (units blockIdx.x, blockIdx.x + gridDim.x, ...): digits of
-// LEVEL into the LDS histogram h[2][STEIN_HIST_BINS] (zeroed by the caller), given the prefixes the earlier levels fixed
+// one histogram pass of a workgroup over a share of the block (units vb, vb + nvb, ... of "virtual workgroup" vb of nvb):
+// digits of LEVEL into the LDS histogram h[2][STEIN_HIST_BINS] (zeroed by the caller), given the prefixes the earlier levels fixed
 template <int LEVEL, bool SYM>
 __device__ __forceinline__ void hist_pass_body(const float* __restrict__ D, long ldD, int n_local, int n, u32* h, u32 pa, u32 pb,
-                                               bool two) {
+                                               bool two, long vb, long nvb) {
   const int lane = threadIdx.x & 63;
   // one unit = one [128][32] tile of the tile-major block (16 KB, 4 x 16 B per thread); SYM skips the tiles that lie
   // entirely below the diagonal.  (Keeping the loads of two more units in flight -- three register sets in rotation --
@@ -277,13 +277,38 @@ __device__ __forceinline__ void hist_pass_body(const float* __restrict__ D, long
   const long ntc = ldD >> 5;
   const int ntr = (n_local + DT_ROWS - 1) / DT_ROWS, ncol_tiles = (n + DT_COLS - 1) / DT_COLS;
   const long units = (long)ntr * ncol_tiles;
-  for (long u = blockIdx.x; u < units; u += gridDim.x) {
+  for (long u = vb; u < units; u += nvb) {
     const int ti = (int)(u / ncol_tiles), tj = (int)(u - (long)ti * ncol_tiles);
     if (SYM && tj * DT_COLS + DT_COLS <= ti * DT_ROWS) continue;
     const float* tile = D + ((size_t)ti * ntc + tj) * DT_ELEMS;
     float4 v4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const float4*>(tile + (threadIdx.x + 256 * q) * 4);
+    // Interior unit: every entry exists and (SYM) lies strictly above the diagonal -- no per-entry bounds, no per-entry
+    // weight.  All but the O(n / 32) units along the edges and the diagonal take this path; with the per-entry tests in
+    // front of every count the pass ran at 2.5 TB/s, bound by its own instruction count (round 3: 37 instructions per entry).
+    const bool interior = ti * DT_ROWS + DT_ROWS <= n_local && tj * DT_COLS + DT_COLS <= n &&
+                          (!SYM || tj * DT_COLS >= ti * DT_ROWS + DT_ROWS);
+    if (interior) {
+      constexpr u32 W = SYM ? 2u : 1u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x[4] = {v4[q].x, v4[q].y, v4[q].z, v4[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const u32 key = f32_key(x[e]);
+          if (LEVEL == 0) {
+            hist_add(h, key >> 21, true, lane, W);
+          } else {
+            const u32 digit = LEVEL == 1 ? ((key >> 10) & 2047u) : (key & 1023u);
+            const u32 hi = LEVEL == 1 ? (key >> 21) : (key >> 10);
+            if (hi == pa) atomicAdd(&h[digit], W);
+            if (two && hi == pb) atomicAdd(&h[STEIN_HIST_BINS + digit], W);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = threadIdx.x + 256 * q;          // float4 index inside the tile: row f / 8, columns 4 (f & 7) ..
@@ -333,7 +358,7 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
     pa = st->prefix[0]; pb = st->prefix[1];
     two = st->diverged != 0u;
   }
-  hist_pass_body<LEVEL, SYM>(D, ldD, n_local, n, h, pa, pb, two);
+  hist_pass_body<LEVEL, SYM>(D, ldD, n_local, n, h, pa, pb, two, blockIdx.x, gridDim.x);
   __syncthreads();
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
     if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
@@ -344,77 +369,100 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
 
 // The whole chained radix select of the fused symmetric call in ONE launch, for blocks small enough that the launches
 // themselves were the cost (n <= HIST_ALL_MAX_N: when the window hit -- the usual case -- three launches returned at once,
-// a few microseconds each).  Here the workgroups of the one launch (all resident: the host keeps the grid to 2 per CU) meet
-// at a barrier behind each level: an arrival counter, and the LAST workgroup to arrive resolves the level once for
-// everybody (chain_resolve with device-scope loads: the other workgroups' histogram atomics were acknowledged before they
-// drew their ticket), publishes the select state in FuseState::pub and opens the gate.  The grid (at most 512 workgroups of
-// 21 KB LDS and < 128 registers) fits the chip several times over, so a workgroup that is not resident yet is waiting for
-// somebody else's kernel to leave, not for the spinning ones.  The spin is bounded all the same (~0.3 s): a workgroup that
-// gives up sets FuseState::gave_up and the step's bandwidth is written as NaN -- a wrong median is never returned.
+// a few microseconds each).  The workgroups of the one launch meet behind each level.
+//
+// No workgroup ever waits for one that has not started (round 3's form assumed that the whole grid was resident: two
+// processes on a card, or a stream with a CU mask, could leave the resident workgroups spinning for absent ones).  The work
+// of a level is cut into G = HIST_ALL_VBLOCKS "virtual workgroups" (virtual workgroup v takes units v, v + G, ...), and the
+// REAL workgroups draw them from FuseState::draw[level] until none is left; after its last one a workgroup flushes its LDS
+// histogram into the global one (device-scope atomics, acknowledged: s_waitcnt vmcnt(0)) and adds the number of virtual
+// workgroups it took to FuseState::done[level].  The add that completes G makes its workgroup the level's resolver: it walks
+// the global histogram once (chain_resolve, device-scope loads), publishes the select state in FuseState::pub and raises
+// FuseState::gen.  The others wait for gen.  A waiting workgroup therefore only ever waits for virtual workgroups that were
+// DRAWN -- by running workgroups, which never wait before they report them done -- so every level completes with one
+// resident workgroup as well as with 512, and a workgroup that starts late finds every counter exhausted and falls through.
+// With the whole grid resident (the normal case) every workgroup draws exactly one virtual workgroup per level: the same
+// split of the work as a static one, for one extra atomic round trip per level.
+// The wait is bounded all the same (a hardware fault is the only way to exhaust it): FuseState::gave_up turns the
+// step's bandwidth into NaN -- a wrong median is never returned -- and raises the device's error word in page-locked host
+// memory, which the next call of the C ABI on this device reports as STEIN_E_HIP (stein_take_device_error).
 constexpr int HIST_ALL_MAX_N = 4096;
-constexpr int HIST_SPIN_MAX = 1 << 20;
+constexpr int HIST_SPIN_MAX = 1 << 22;
 constexpr int HIST_BLOCKS = 2048;      // workgroups of a histogram pass (C3, every step a miss: 0.61 ms of select with 2048, 0.77 with 1024, 1.17 with 512)
-constexpr int HIST_ALL_BLOCKS = 512;   // .. of k_hist_all, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
-__device__ __forceinline__ ChainState hist_level_barrier(FuseState* fs, u32 nblk, u32 generation, const u64* hist_all, int levels,
-                                                        const SelState* st) {
-  __shared__ u32 s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(&fs->bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation * nblk - 1u ? 1u : 0u;
-  __syncthreads();
-  ChainState cs;
-  if (s_last) {
-    cs = chain_resolve<true>(hist_all, levels, st);
-    if (threadIdx.x == 0) {
-      const u32 w[7] = {cs.prefix[0], cs.prefix[1], (u32)cs.rank[0], (u32)(cs.rank[0] >> 32), (u32)cs.rank[1], (u32)(cs.rank[1] >> 32),
-                        cs.two ? 1u : 0u};
-#pragma unroll
-      for (int k = 0; k < 7; ++k) __hip_atomic_store(&fs->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&fs->bar[1], generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return cs;
-  }
-  if (threadIdx.x == 0) {
-    int spin = 0;
-    for (; spin < HIST_SPIN_MAX && load_fresh(&fs->bar[1]) < generation; ++spin) __builtin_amdgcn_s_sleep(8);
-    if (spin == HIST_SPIN_MAX) __hip_atomic_store(&fs->gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  u32 w[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) w[k] = load_fresh(&fs->pub[k]);
-  cs.prefix[0] = w[0]; cs.prefix[1] = w[1];
-  cs.rank[0] = (u64)w[2] | ((u64)w[3] << 32); cs.rank[1] = (u64)w[4] | ((u64)w[5] << 32);
-  cs.two = w[6] != 0u;
-  return cs;
-}
+constexpr int HIST_ALL_VBLOCKS = 512;  // virtual workgroups of k_hist_all = its grid, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
 __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, long ldD, int n, const SelState* st, u64* hist_all,
                                                   const u32* __restrict__ hit, const u32* __restrict__ skip_l0, HistFinal fin,
-                                                  FuseState* fs /* bar[], pub[] zero at launch */) {
+                                                  FuseState* fs /* draw[], done[], gen, pub[] zero at launch */, u32 nvb,
+                                                  u32* errword /* page-locked host memory, or NULL */) {
   if (*hit) return;   // the speculative window already produced this step's median
   __shared__ u32 h[2 * STEIN_HIST_BINS];
+  __shared__ u32 s_v, s_last;
   const int first = *skip_l0 == 0u ? 0 : 1;   // level 0 may have been taken by the distance kernel (an earlier launch)
   ChainState cs = chain_resolve<false>(hist_all, first, st);
   for (int level = first; level < STEIN_HIST_LEVELS; ++level) {
     for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
+    if (threadIdx.x == 0) s_v = __hip_atomic_fetch_add(&fs->draw[level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (level == 0) hist_pass_body<0, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two);
-    else if (level == 1) hist_pass_body<1, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two);
-    else hist_pass_body<2, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two);
-    __syncthreads();
-    u64* hl = hist_all + (size_t)level * 2 * STEIN_HIST_BINS;
-    for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
-      if (h[b]) atomicAdd(&hl[b], (u64)h[b]);
-    if (level + 1 < STEIN_HIST_LEVELS) cs = hist_level_barrier(fs, gridDim.x, (u32)(level - first + 1), hist_all, level + 1, st);
-  }
-  if (fin.done && last_workgroup_out(fin.done, gridDim.x)) {
-    resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
-    if (threadIdx.x == 0 && load_fresh(&fs->gave_up)) {   // a workgroup left a barrier unopened: no median, and loudly so
-      fin.st->median = fin.st->h2 = __builtin_nanf("");
-      if (fin.h2_out) *fin.h2_out = __builtin_nanf("");
+    u32 v = s_v, took = 0u;
+    while (v < nvb) {
+      __syncthreads();   // everybody has read s_v
+      // the next draw flies under this virtual workgroup's pass (with the whole grid resident it comes back >= nvb)
+      if (threadIdx.x == 0) s_v = __hip_atomic_fetch_add(&fs->draw[level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (level == 0) hist_pass_body<0, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
+      else if (level == 1) hist_pass_body<1, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
+      else hist_pass_body<2, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
+      ++took;
+      __syncthreads();
+      v = s_v;
     }
+    if (took) {
+      u64* hl = hist_all + (size_t)level * 2 * STEIN_HIST_BINS;
+      for (int b = threadIdx.x; b < (cs.two ? 2 : 1) * STEIN_HIST_BINS; b += 256)
+        if (h[b]) atomicAdd(&hl[b], (u64)h[b]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's histogram atomics have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_last = took && __hip_atomic_fetch_add(&fs->done[level], took, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + took == nvb ? 1u : 0u;
+    __syncthreads();
+    const bool last = s_last != 0u;
+    if (level + 1 == STEIN_HIST_LEVELS) {   // behind the last level: the resolver finishes the select, everybody else leaves
+      if (last) {
+        resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
+        if (threadIdx.x == 0 && load_fresh(&fs->gave_up)) {   // a wait ran out somewhere: no median, and loudly so
+          fin.st->median = fin.st->h2 = __builtin_nanf("");
+          if (fin.h2_out) *fin.h2_out = __builtin_nanf("");
+          if (errword) __hip_atomic_store(errword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      return;
+    }
+    const u32 want = (u32)(level - first + 1);
+    if (last) {
+      cs = chain_resolve<true>(hist_all, level + 1, st);
+      if (threadIdx.x == 0) {
+        const u32 w[4] = {cs.prefix[0], cs.prefix[1], (u32)cs.rank[0], (u32)cs.rank[1]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __hip_atomic_store(&fs->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&fs->gen, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (threadIdx.x == 0) {
+      int spin = 0;
+      for (; spin < HIST_SPIN_MAX && load_fresh(&fs->gen) < want; ++spin) __builtin_amdgcn_s_sleep(8);
+      if (spin == HIST_SPIN_MAX) __hip_atomic_store(&fs->gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // (a workgroup that started late may read the state of a LATER level here, or a mix of two: then that later level was
+    // complete before the read, its draw counter is exhausted, and the state is never used)
+    u32 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = load_fresh(&fs->pub[k]);
+    cs.prefix[0] = w[0]; cs.prefix[1] = w[1];
+    cs.rank[0] = (u64)w[2]; cs.rank[1] = (u64)w[3];
+    cs.two = w[0] != w[1];
   }
 }
 
@@ -1644,6 +1692,60 @@ extern "C" int stein_rank_finish(const void* theta_all, const void* score_all, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// device error word: one u32 per device in page-locked host memory that a kernel raises when it had to give up (today
+// only k_hist_all's bounded wait).  The host reads it without touching the stream at the start of the next fused call or
+// optimizer apply on that device and turns it into STEIN_E_HIP; the step that raised it has already written NaN into its
+// bandwidth, so nothing wrong was consumed silently in between.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 64;
+static u32* g_errword[MAX_DEVICES];
+static int device_error_word(u32** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) { *out = nullptr; return STEIN_OK; }
+  u32* w = __atomic_load_n(&g_errword[dev], __ATOMIC_ACQUIRE);
+  if (!w) {
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable));
+    *(volatile u32*)p = 0u;
+    u32* expect = nullptr;
+    if (!__atomic_compare_exchange_n(&g_errword[dev], &expect, (u32*)p, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+      (void)hipHostFree(p);   // another thread was first
+      w = expect;
+    } else {
+      w = (u32*)p;
+    }
+  }
+  *out = w;
+  return STEIN_OK;
+}
+// STEIN_E_HIP if a kernel of an EARLIER call on the current device raised the error word (and lowers it again)
+int stein_take_device_error(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return STEIN_OK;
+  u32* w = __atomic_load_n(&g_errword[dev], __ATOMIC_ACQUIRE);
+  if (!w || !*(volatile u32*)w) return STEIN_OK;
+  *(volatile u32*)w = 0u;
+  return fail(STEIN_E_HIP, "an earlier step on device %d gave up inside k_hist_all (bounded wait exhausted): its bandwidth and "
+                           "everything computed from it are NaN", dev);
+}
+// test hooks (per calling thread; tests/test_gpu_spec.py): launch k_hist_all with this many workgroups instead of one per
+// virtual workgroup (0 = default); raise the current device's error word as a kernel would
+static thread_local int g_hist_all_grid = 0;
+extern "C" int stein_debug_hist_all_grid(int blocks) {
+  if (blocks < 0 || blocks > 65535) return fail(STEIN_E_BADARG, "blocks %d", blocks);
+  g_hist_all_grid = blocks;
+  return STEIN_OK;
+}
+extern "C" int stein_debug_raise_device_error(void) {
+  u32* w = nullptr;
+  int rc = device_error_word(&w);
+  if (rc) return rc;
+  if (w) *(volatile u32*)w = 1u;
+  return STEIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage timing of the fused call (profiling aid; per calling thread, like the last-error string)
 // ------------------------------------------------------------------------------------------------
 
@@ -1682,6 +1784,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   SteinLayout L;
   int rc = stein_make_layout(n_local, n, d, dtype, flags, &L);
   if (rc) return rc;
+  if ((rc = stein_take_device_error())) return rc;   // a kernel of an earlier call on this device gave up: say so now
   if (dtype == STEIN_BF16 && !(flags & STEIN_FLAG_X3))
     return fail(STEIN_E_UNSUPPORTED, "bf16 inputs run on the bf16-MFMA kernels: pass STEIN_FLAG_X3");
   if (ws_bytes < L.total) return fail(STEIN_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
@@ -1769,11 +1872,15 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   // chained radix select: three passes that resolve the earlier levels themselves; the last workgroup of the third
   // resolves the rest.  Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
   const HistFinal fin{(SelState*)sel, spec, h2_out, &fuse->done_hist, (float)log((double)n)};
-  if (!solo && n <= HIST_ALL_MAX_N) {   // one launch for all three levels (in-launch barriers; at most 4 workgroups per CU)
+  if (!solo && n <= HIST_ALL_MAX_N) {   // one launch for all three levels (k_hist_all: in-launch level barriers that need no co-residency)
     const long units = ((n + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);
-    const int blocks = (int)(units < HIST_ALL_BLOCKS ? units : HIST_ALL_BLOCKS);
+    const int nvb = (int)(units < HIST_ALL_VBLOCKS ? units : HIST_ALL_VBLOCKS);
+    const int blocks = g_hist_all_grid > 0 ? g_hist_all_grid : nvb;   // (test hook: any grid >= 1 must give the same median)
+    u32* errword = nullptr;
+    if ((rc = device_error_word(&errword))) return rc;
     hipLaunchKernelGGL(k_hist_all, dim3(blocks), dim3(256), 0, s, (const float*)D, (long)L.ld_dist, (int)n,
-                       (const SelState*)sel, (u64*)hist, (const u32*)&spec->hit, (const u32*)&spec->skip_l0, fin, fuse);
+                       (const SelState*)sel, (u64*)hist, (const u32*)&spec->hit, (const u32*)&spec->skip_l0, fin, fuse,
+                       (u32)nvb, errword);
     LAUNCH_CHECK("k_hist_all");
   } else
   for (int lv = 0; lv < (solo ? 0 : STEIN_HIST_LEVELS); ++lv)
@@ -1821,6 +1928,7 @@ extern "C" int stein_apply_adagrad(void* theta, const void* phi, int phi_dtype, 
   if (!phi || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (count < 1) return fail(STEIN_E_SHAPE, "count < 1");
   if (int rc = check_apply_dtypes(state_dtype, phi_dtype)) return rc;
+  if (int rc = stein_take_device_error()) return rc;
   if (state_dtype == STEIN_F32)
     return apply_adagrad_t<float, float>(theta, phi, hist, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, alpha, eps,
                                          first_step, step_out, stream);
@@ -1849,6 +1957,7 @@ extern "C" int stein_apply_adam(void* theta, const void* phi, int phi_dtype, voi
   if (!phi || !mu || !nu) return fail(STEIN_E_BADARG, "NULL pointer");
   if (count < 1 || t < 1) return fail(STEIN_E_SHAPE, "count < 1 or t < 1");
   if (int rc = check_apply_dtypes(state_dtype, phi_dtype)) return rc;
+  if (int rc = stein_take_device_error()) return rc;
   if (state_dtype == STEIN_F32)
     return apply_adam_t<float, float>(theta, phi, mu, nu, count, sqnorm_dev, clip_scale_host, clip_threshold, lr, beta1,
                                       beta2, eps, t, step_out, stream);

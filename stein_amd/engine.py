@@ -18,7 +18,6 @@ cross a link.  Mirrors the single call at
 stein/samplers/abstract_stein_sampler.py:103-105 (K, dK = kernel_and_grad; phi).
 """
 import ctypes
-import os
 
 import torch
 
@@ -198,7 +197,7 @@ class SvgdEngine:
     _full_distance_image = False   # set by scratch/ab.py for -DSTEIN_NO_UPPER builds (the mirrored image of round 1)
 
     def __init__(self, n, d, device="cuda", group=None, stages=None, x3=None, dtype=torch.float32, small=True,
-                 window=True, force_collectives=False, comm="auto", tile_distance=False):
+                 window=True, force_collectives=False, comm="auto", tile_distance=False, dist_window=None):
         self.n, self.d = int(n), int(d)
         # dtype of the theta / score tensors handed to compute_phi: float32, or bfloat16 (BASELINE config 2: the
         # values are used as they are, K is rounded to bf16, one bf16 MFMA per product, fp32 accumulation)
@@ -207,9 +206,10 @@ class SvgdEngine:
         self.dtype = dtype
         # x3 (default): both GEMMs run on the 16-bit matrix cores with every fp32 operand scaled by a power of two and
         # split into two fp16 terms -- fp32-level accuracy at a fraction of the fp32-MFMA time (stein_x3.hip).
-        # x3=False (or STEIN_X3=0) selects the fp32-input MFMA kernels (an exact k-ordered fmaf chain).
+        # x3=False selects the fp32-input MFMA kernels (an exact k-ordered fmaf chain).  None = the default (split path).
+        # Constructor arguments are the only switches: neither this module nor the library reads the environment.
         if x3 is None:
-            x3 = os.environ.get("STEIN_X3", "1") not in ("0", "", "false")
+            x3 = True
         self.x3 = bool(x3) or dtype == torch.bfloat16   # bf16 inputs only exist on the bf16-MFMA kernels
         # small=False: the fused call never takes the one-kernel path for n <= 160 (tests of the tiled kernels)
         # window=False: the fused call never uses the speculative median window (every step pays the radix-select passes;
@@ -221,7 +221,7 @@ class SvgdEngine:
         # several ranks: use the speculative median window (ONE 512 KB all-reduce and a hit-flag read-back per step
         # instead of three histogram all-reduces and two passes over the local distance block) when the block is large
         # enough for that to pay (>= 2^24 entries; every collective costs ~30 us of host time from Python, and the
-        # read-back no longer leaves a bubble on the stream: _sharded_step); STEIN_DIST_WINDOW=0/1 forces it
+        # read-back no longer leaves a bubble on the stream: _sharded_step); dist_window=True / False forces it
         self.dist_window = False
         self.window_hit = None
         self.device = torch.device(device)
@@ -260,8 +260,7 @@ class SvgdEngine:
         self.median = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
         if self.sharded and hasattr(self.stages, "spec_begin"):
-            env = os.environ.get("STEIN_DIST_WINDOW", "")
-            self.dist_window = env == "1" or (env != "0" and self.n_local * self.n >= (1 << 24))
+            self.dist_window = bool(dist_window) if dist_window is not None else self.n_local * self.n >= (1 << 24)
         if self.sharded:
             self.T_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)
             self.G_all = torch.empty(self.n, self.d, dtype=dtype, device=dev)

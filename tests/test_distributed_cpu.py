@@ -73,7 +73,6 @@ def test_sharded_protocol_matches_single_rank(tmp_path, world, n, d):
 def _worker_window(rank, world, port, n, d, steps, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ["STEIN_DIST_WINDOW"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from stein_amd import _lib
@@ -81,7 +80,7 @@ def _worker_window(rank, world, port, n, d, steps, out_dir):
         from oracle.staged_model import NumpyStages
         rng = np.random.default_rng(5)
         T, G, V = rng.normal(size=(n, d)), rng.normal(size=(n, d)), 1e-3 * rng.normal(size=(n, d))
-        eng = SvgdEngine(n, d, device="cpu", group=dist.group.WORLD, stages=NumpyStages(_lib.workspace_layout))
+        eng = SvgdEngine(n, d, device="cpu", group=dist.group.WORLD, stages=NumpyStages(_lib.workspace_layout), dist_window=True)
         assert eng.dist_window
         sl = slice(eng.row0, eng.row0 + eng.n_local)
         sc = torch.tensor(G[sl], dtype=torch.float32).contiguous()

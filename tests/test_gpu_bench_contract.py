@@ -33,11 +33,24 @@ def test_bench_line_has_the_contract_keys(cuda):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["value"] > 0
-    # round 3: the fraction is named three ways, the host baseline says how many threads / cores it ran on and is timed on
-    # one thread as well, the distance pass reports its HBM write rate
-    for key in ("frac_executed", "frac_algorithmic", "mfma_busy_frac"):
+    # `achieved` / `frac` are the ALGORITHMIC 4 n_local n d flops per launch over the kernel's mean duration
+    # (round 4; rounds 1-3 put the executed flops there).  The executed fraction, the counter reading and the fp32-peak view
+    # stand beside it under their own names.
+    for key in ("frac_executed", "frac_algorithmic", "mfma_busy_frac", "frac_vs_fp32_mfma_peak", "algorithmic_flops_per_launch",
+                "ms_per_launch"):
         assert key in roof, key
-    assert roof["frac_executed"] == roof["frac"] and 0.0 < roof["frac_algorithmic"] <= roof["frac_executed"]
+    assert roof["frac_algorithmic"] == roof["frac"] and roof["frac"] <= roof["frac_executed"] <= 1.0
+    n, d = b["config"]["n"], b["config"]["d"]
+    assert roof["algorithmic_flops_per_launch"] == 4.0 * n * n * d
+    alg = roof["algorithmic_flops_per_launch"] / (roof["ms_per_launch"] * 1e-3) / 1e12
+    assert abs(roof["achieved"] - alg) <= 1e-9 * alg
+    assert abs(roof["frac_vs_fp32_mfma_peak"] - alg / 157.3) <= 1e-9 * alg
+    # every timed entry says how far the wall time per step is from the GPU time its HIP events bracket
+    for key in ("events_ms", "wall_minus_events_ms", "host_stall_suspected"):
+        assert key in b, key
+    assert abs(b["wall_minus_events_ms"] - (b["ms_per_step"] - b["events_ms"])) < 2e-4
+    # the host baseline says how many threads / cores it ran on and is timed on one thread as well, the distance pass reports
+    # its HBM write rate
     for key in ("blas_threads", "logical_cpus", "physical_cores", "one_thread"):
         assert key in cpu, key
     assert cpu["one_thread"]["cores"] == 1 and cpu["one_thread"]["value"] > 0 and cpu["cores"] == cpu["blas_threads"]
@@ -53,4 +66,5 @@ def test_train_on_batch_entry(cuda):
     import bench
     ent = bench.train_on_batch_entry(torch, cuda, steps=6, warmup=3)
     assert ent["finite"] and ent["ms_per_step"] > 0 and ent["window"]["timed_steps"] == 6
+    assert abs(ent["wall_minus_events_ms"] - (ent["ms_per_step"] - ent["events_ms"])) < 2e-4
     assert 0 <= ent["window"]["hits"] <= 6

@@ -69,7 +69,6 @@ def test_two_ranks_match_one(cuda, tmp_path, n, d):
 
 def _worker_window(rank, world, port, n, d, steps, out_dir):
     sys.path.insert(0, ROOT)
-    os.environ["STEIN_DIST_WINDOW"] = "1"          # force the cross-rank speculative window at this small size
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -82,7 +81,7 @@ def _worker_window(rank, world, port, n, d, steps, out_dir):
         sl = slice(rank * nl, (rank + 1) * nl)
         theta = torch.tensor(T[sl], dtype=torch.float32, device="cuda:0")
         score = torch.tensor(G[sl], dtype=torch.float32, device="cuda:0")
-        eng = SvgdEngine(n, d, device="cuda:0", group=dist.group.WORLD)
+        eng = SvgdEngine(n, d, device="cuda:0", group=dist.group.WORLD, dist_window=True)   # forced: small block
         assert eng.dist_window
         gd = AdagradGradientDescent(learning_rate=1e-3)
         h2s, hits = [], []

@@ -56,11 +56,10 @@ def _worker(rank, port, n, d, steps, out_dir):
         import itertools
         for comm, x3 in itertools.product(("torch", "native"), (False, True)):
             for form in ("radix", "window"):
-                os.environ["STEIN_DIST_WINDOW"] = "1" if form == "window" else "0"
                 theta = torch.tensor(T0, dtype=torch.float32, device=dev)
                 score = torch.tensor(G0, dtype=torch.float32, device=dev)
                 eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True, x3=x3, small=False,
-                                 comm=comm)
+                                 comm=comm, dist_window=(form == "window"))
                 assert eng.sharded and eng.dist_window == (form == "window") and eng.comm == comm
                 gd = AdagradGradientDescent(learning_rate=1e-3)
                 ref = SvgdEngine(n, d, device=dev, x3=x3, small=False)       # single-rank staged path, same inputs
@@ -81,11 +80,10 @@ def _worker(rank, port, n, d, steps, out_dir):
                     theta_err=float((theta - theta_r).abs().max() / theta_r.abs().max()))
                 eng.close()
         # bf16 particles (BASELINE config 2's input format) and the optional dK output through stein_rank_step
-        os.environ["STEIN_DIST_WINDOW"] = "1"
         tb = torch.tensor(T0, dtype=torch.float32, device=dev).bfloat16()
         gb = torch.tensor(G0, dtype=torch.float32, device=dev).bfloat16()
         eng = SvgdEngine(n, d, device=dev, group=dist.group.WORLD, force_collectives=True, dtype=torch.bfloat16, small=False,
-                         comm="native")
+                         comm="native", dist_window=True)
         ref = SvgdEngine(n, d, device=dev, dtype=torch.bfloat16, small=False)
         dK, dK_r = torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
         errs = []

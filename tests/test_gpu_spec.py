@@ -147,3 +147,50 @@ def test_one_launch_select_without_the_window(cuda, n, d, dtype):
         assert float(fused.h2) == float(staged.h2) and float(fused.h2) > 0.0, (step, float(fused.h2), float(staged.h2))
         assert torch.equal(pf, ps) and float(fused.sqnorm) == float(staged.sqnorm), step
         assert _spec_state(fused)["hit"] == 0
+
+
+@pytest.mark.parametrize("grid", [1, 3, 40, 4096])
+def test_one_launch_select_needs_no_co_residency(cuda, grid):
+    """k_hist_all's level barriers never wait for a workgroup that has not started: the work of a level is cut into 512
+    virtual workgroups that the running workgroups DRAW (FuseState::draw / done / gen).  Forced here: the launch gets 1, 3
+    or 40 workgroups (far fewer than the 512 virtual ones: the few present take them all over) or 4096 (more than the chip
+    holds at once: the late ones find every counter exhausted and fall through).  The median -- hence bandwidth, phi and
+    |phi|^2 -- equals the staged calls' bit for bit every time, and no error is raised."""
+    n, d = 2304, 24                                                  # 18 x 72 = 1296 units of [128][32]
+    g = torch.Generator(device="cpu").manual_seed(grid)
+    fused = SvgdEngine(n, d, device=cuda, window=False, small=False)
+    staged = SvgdEngine(n, d, device=cuda, small=False)
+    _lib.call("stein_debug_hist_all_grid", grid)
+    try:
+        for step in range(3):
+            T = (torch.randn(n, d, generator=g) * (1.0 + 2.0 * step)).to(cuda)
+            G = torch.randn(n, d, generator=g).to(cuda)
+            pf = fused.compute_phi(T, G).clone()
+            ps = _staged(staged, T, G).clone()
+            torch.cuda.synchronize()
+            assert float(fused.h2) == float(staged.h2) and float(fused.h2) > 0.0, (grid, step)
+            assert torch.equal(pf, ps) and float(fused.sqnorm) == float(staged.sqnorm), (grid, step)
+    finally:
+        _lib.call("stein_debug_hist_all_grid", 0)
+    _lib.call("stein_take_device_error")                             # nothing gave up
+
+
+def test_device_error_word_is_reported_by_the_next_call(cuda):
+    """A kernel that gives up raises the device's error word (page-locked host memory); the next fused call or optimizer
+    apply on that device returns STEIN_E_HIP once instead of queueing more work on poisoned state, then things go on."""
+    from stein_amd.optimizers import AdagradGradientDescent
+    n, d = 640, 8
+    T, G = torch.randn(n, d, device=cuda), torch.randn(n, d, device=cuda)
+    eng = SvgdEngine(n, d, device=cuda)
+    eng.compute_phi(T, G)
+    _lib.call("stein_debug_raise_device_error")
+    with pytest.raises(_lib.SteinHipError, match="k_hist_all"):
+        eng.compute_phi(T, G)
+    phi = eng.compute_phi(T, G)                                      # reported once; the word is lowered again
+    _lib.call("stein_debug_raise_device_error")
+    gd = AdagradGradientDescent(learning_rate=1e-3)
+    with pytest.raises(_lib.SteinHipError, match="k_hist_all"):
+        gd.apply_(T, phi, eng.sqnorm)
+    gd.apply_(T, phi, eng.sqnorm)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(T).all())
