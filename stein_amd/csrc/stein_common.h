@@ -135,16 +135,15 @@ static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
 // 1024 of them waiting on their stores the ticket cost more than the launch it saved).  Zeroed by the fused call's first
 // kernel; each ticket also resets itself.
 struct FuseState {
-  u32 done_colmax, done_hist, done_finish;
+  u32 done_colmax, done_finish;
   // k_hist_all (the chained select in one launch, steinhip.hip).  The work of a level is cut into G "virtual workgroups";
   // whichever real workgroups are running DRAW them from draw[level], so a level completes with any number of resident
   // workgroups and nobody ever waits for a workgroup that has not started.
   u32 draw[3];     // next virtual workgroup of each level
   u32 done[3];     // virtual workgroups of each level whose counts have reached the global histogram
   u32 gen;         // levels resolved and published since the launch
-  u32 pub[4];      // the select state the resolver published: prefix[2], rank[2] (n <= 4096: the ranks fit 32 bits)
+  u32 pub[6];      // the select state the resolver published: prefix[2], rank[2] as halves
   u32 gave_up;     // a bounded wait ran out (cannot happen by construction; the bandwidth becomes NaN and the host is told)
-  u32 pad[1];
 };
 static_assert(sizeof(FuseState) == 64, "FuseState must stay 64 bytes");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;

@@ -149,13 +149,84 @@ __device__ __forceinline__ void dp_flush(DpWin& sx, SpecState* __restrict__ spec
   sx.qn = 0u;
 }
 
+// a step without a window takes the level-0 histogram here (the LDS histogram occupies the window queues' 8 KB; the first
+// __syncthreads of the segment loop -- or the one in front of the final flush -- orders the zeroing before the counting)
+#define DP_HIST_SETUP                                                                                                   \
+  const bool hist = hist0 != nullptr && !window;                                                                        \
+  DpHist hx;                                                                                                            \
+  hx.hl = reinterpret_cast<u32*>(smem + DP_PANEL + 8 * DP_STAGE);                                                       \
+  hx.packed = 0ull; hx.base = 0u; hx.wt = SYM ? 2u : 1u; hx.nacc = 0u; hx.have = false;                                 \
+  if (hist)                                                                                                             \
+    for (int b = t; b < STEIN_HIST_BINS; b += DP_THREADS) hx.hl[b] = 0u
+// the workgroup's histogram -> the global level-0 histogram (every thread of the workgroup gets here)
+#define DP_HIST_FINISH                                                                                                  \
+  if (hist) {                                                                                                           \
+    dp_hist_flush(hx, lane);                                                                                            \
+    __syncthreads();                                                                                                    \
+    for (int b = t; b < STEIN_HIST_BINS; b += DP_THREADS)                                                               \
+      if (hx.hl[b]) atomicAdd(reinterpret_cast<unsigned long long*>(&hist0[b]), (unsigned long long)hx.hl[b]);          \
+  }
+static_assert(8 * DP_QBYTES == 4 * STEIN_HIST_BINS, "the level-0 histogram lives in the window queues' LDS");
+
+// ---- level-0 radix-select histogram from the epilogue (a step WITHOUT a median window: the first two steps of a run, the
+// staged calls of a sharded run's radix form, STEIN_FLAG_NO_WINDOW) ------------------------------------------------------
+// Round 3 left this to a k_hist<0> pass over D (0.15 ms at C3, a third of what a miss costs).  The workgroup's histogram
+// lives in the 8 KB the window queues would occupy (a step has a window or a histogram, never both).  The distances of a
+// strip fall into a few neighbouring level-0 digits (a digit is a quarter octave), so every lane counts into eight 8-bit
+// slots of one 64-bit register for the digits [base, base + 8) around the first value its wave saw (nine VALU
+// instructions per entry, no LDS traffic); the wave sums the slots every three strips (<= 192 per slot) and adds them to
+// the LDS histogram with eight atomics.  A value outside the slots -- and every entry of a diagonal strip, whose weights
+// differ per entry -- goes to the LDS histogram directly.  The workgroup adds its histogram to the global one at the end.
+struct DpHist {
+  u32* hl;       // LDS: STEIN_HIST_BINS counters of the workgroup
+  u64 packed;    // this lane's eight 8-bit slots
+  u32 base;      // first RAW digit (bits >> 21 of a positive float, 0 .. 1016) of the slots (wave-uniform)
+  u32 wt;        // weight of an entry of a regular strip (2: it also stands for its mirror image)
+  u32 nacc;      // regular strips counted into `packed` since the last flush (wave-uniform)
+  bool have;     // base has been chosen
+};
+__device__ __forceinline__ u32 dp_key_digit(u32 rawdigit) {   // bits >> 21 -> level-0 digit of the order-preserving key
+  return rawdigit >= 1024u ? 2047u - rawdigit : rawdigit + 1024u;
+}
+__device__ __forceinline__ void dp_hist4(DpHist& hx, const float (&v)[4]) {
+  bool far = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const u32 off = (__float_as_uint(v[e]) >> 21) - hx.base;   // a negative value has rawdigit >= 1024 > base + 7: "far"
+    const bool near = off < 8u;
+    hx.packed += near ? 1ull << (8u * (off & 7u)) : 0ull;
+    far |= !near;
+  }
+  if (__builtin_expect(far, 0)) {   // (the digits are formed again here: four registers less across the hot path)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32 dg = __float_as_uint(v[e]) >> 21;
+      if (dg - hx.base >= 8u) atomicAdd(&hx.hl[dp_key_digit(dg)], hx.wt);
+    }
+  }
+}
+__device__ __forceinline__ void dp_hist_flush(DpHist& hx, int lane) {
+  if (hx.nacc == 0u) return;
+  u64 x0 = hx.packed & 0x00ff00ff00ff00ffull, x1 = (hx.packed >> 8) & 0x00ff00ff00ff00ffull;   // slots 0,2,4,6 / 1,3,5,7 as 16-bit fields
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { x0 += __shfl_xor(x0, o); x1 += __shfl_xor(x1, o); }        // <= 64 lanes x 192: fits 16 bits
+  if (lane < 8) {
+    const u32 c = (u32)(((lane & 1) ? x1 : x0) >> (16 * (lane >> 1))) & 0xffffu;
+    if (c) atomicAdd(&hx.hl[1024u + hx.base + (u32)lane], c * hx.wt);
+  }
+  hx.packed = 0ull;
+  hx.nacc = 0u;
+}
+
 template <bool SYM, int NP>
 __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __restrict__ T3, int ntk,
                                                                   const float* __restrict__ r, float* __restrict__ D,
                                                                   int row0, int tiles_m, int tiles_n, long ldD,
                                                                   const float* __restrict__ two_s,
-                                                                  SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
+                                                                  SpecState* __restrict__ spec, u64* __restrict__ spec_buf,
+                                                                  u64* __restrict__ hist0) {
   constexpr int LPS = 2 * NP;                  // streamed loads per k tile: 2 column blocks x NP planes
+  constexpr int DP_HIST_EVERY = 3;             // strips between two flushes of the level-0 slots
   constexpr int W_LATE = 3 * LPS;              // the loads of the three k tiles behind the one waited for stay in flight
   constexpr int W_EARLY = 3 * LPS + 16 + 2;    // ... and the 16 D stores and 2 norm loads issued between its request and its use
   __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS + 16];
@@ -175,9 +246,10 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
     const u32 lk = spec->lo_key, wd = spec->width;
     window = wd != 0u;
     if (window) { sx.lo = lk & 0x7fffffffu; sx.width = wd; }
-    // no window this step: this kernel takes no level-0 histogram, so the k_hist<0> pass over D must run
-    else if (blockIdx.x == 0 && t == 0) spec->skip_l0 = 0u;
+    // no window this step and nowhere to put the level-0 histogram: the k_hist<0> pass over D must run
+    else if (!hist0 && blockIdx.x == 0 && t == 0) spec->skip_l0 = 0u;
   }
+  DP_HIST_SETUP;
 
   // ---- this workgroup's share of the strip order -----------------------------------------------------------------------
   const int G = gridDim.x, p = xcd_remap(blockIdx.x, G);
@@ -307,7 +379,9 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         DP_STAMP(2);
         stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
+#define DP_RI(ib) ri[ib]
 #include "stein_dpanel_epilogue.inc"
+#undef DP_RI
         regular = !diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
         request_norms(snext);                      // ("memory": the strip's stores are issued before this point)
@@ -326,6 +400,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   DP_STAMP_FLUSH(lane);
   DP_STAMP_WG(p, w, lane);
   DP_SLOW_FLUSH(p, w, lane);
+  DP_HIST_FINISH
   if (window) {
     dp_flush(sx, spec, spec_buf, lane);
     if (lane == 0) {
@@ -351,15 +426,18 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
                                                                        const float* __restrict__ r, float* __restrict__ D,
                                                                        int row0, int tiles_m, int tiles_n, long ldD,
                                                                        const float* __restrict__ two_s,
-                                                                       SpecState* __restrict__ spec, u64* __restrict__ spec_buf) {
+                                                                       SpecState* __restrict__ spec, u64* __restrict__ spec_buf,
+                                                                       u64* __restrict__ hist0) {
   constexpr int LPS = 2 * NP;
+  constexpr int DP_HIST_EVERY = 1;
   constexpr int KC = 16 / NP;                  // k tiles of the panel in LDS at a time
   constexpr int W_LATE = 3 * LPS;              // the loads of the three k tiles behind the one waited for stay in flight
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DP_LDS + 512];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   unsigned char* const panel = smem;
   unsigned char* const stg = smem + DP_PANEL + w * DP_STAGE;
+  float* const rn = reinterpret_cast<float*>(smem + DP_LDS);   // norms of the segment's 128 rows
   const long ntc = ldD >> 5;
   const int groups = (ntk + DP_RING - 1) / DP_RING, nchunks = (ntk + KC - 1) / KC;
   const float nts = -*two_s;
@@ -372,8 +450,10 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
     const u32 lk = spec->lo_key, wd = spec->width;
     window = wd != 0u;
     if (window) { sx.lo = lk & 0x7fffffffu; sx.width = wd; }
-    else if (blockIdx.x == 0 && t == 0) spec->skip_l0 = 0u;   // (no level-0 histogram here either)
+    // no window this step and nowhere to put the level-0 histogram: the k_hist<0> pass over D must run
+    else if (!hist0 && blockIdx.x == 0 && t == 0) spec->skip_l0 = 0u;
   }
+  DP_HIST_SETUP;
 
   // the workgroup's share of the strip order: as in k_distance_panel
   const int G = gridDim.x, p = xcd_remap(blockIdx.x, G);
@@ -414,6 +494,8 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
                      : "=&v"(slot[0][0]), "=&v"(slot[1][0]) : "v"(aoff), "s"(src));
       }
     };
+    __syncthreads();                             // nobody still reads the previous segment's row norms
+    if (t < 128) rn[t] = r[row0 + 128 * I + t];  // (visible behind the first chunk's barriers)
     const int rounds = (se + 7) / 8;
     int s = w;                                   // round k: strip 8 k + w
     const u16* cur = strip_base(s < se ? s : 0);
@@ -464,19 +546,18 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
         }
       }
       if (active) {
-        // the norms of the strip's rows and columns: plain loads, here (eight registers each that the K loop needs; the
-        // compiler's wait for them also lands the next strip's first requests -- the chunk boundary behind the epilogue
-        // would have done that anyway)
-        float ri[8];
+        // the norms of the strip's columns: plain loads, here (the compiler's wait for them also lands the next strip's first
+        // requests -- the chunk boundary behind the epilogue would have done that anyway); the row norms come from the
+        // segment's LDS copy one at a time (eight registers less than holding them all: this kernel has none to spare)
         f32x4g rj[2];
-#pragma unroll
-        for (int ib = 0; ib < 8; ++ib) ri[ib] = r[row0 + 128 * I + 16 * ib + li];
         {
           const float* rb = r + 32l * (cfirst + members * s) + 4 * lq;
           rj[0] = *reinterpret_cast<const f32x4g*>(rb);
           rj[1] = *reinterpret_cast<const f32x4g*>(rb + 16);
         }
+#define DP_RI(ib) rn[16 * (ib) + li]
 #include "stein_dpanel_epilogue.inc"
+#undef DP_RI
         (void)diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) dp_flush(sx, spec, spec_buf, lane);
         cur = nxt;
@@ -484,6 +565,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
     }
     stream_wait<0>();                            // the trailing re-reads land before their registers move on
   }
+  DP_HIST_FINISH
   if (window) {
     dp_flush(sx, spec, spec_buf, lane);
     if (lane == 0) {
@@ -501,7 +583,7 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
                      bool any_size) {
   const int np = stein_x3_kind(dtype);
   const int64_t ntk = L.x3_dk / 32;
-  if (level0_only) return false;                                   // the caller wants the level-0 histogram from the epilogue
+  (void)level0_only;                                               // (round 4: the epilogue takes the level-0 histogram too)
   if ((n & 127) || (n_local & 127) || (row0 & 127)) return false;
   // (np * ntk > 16: the panel does not fit 128 KB of LDS -> k_distance_panel_deep walks K in chunks)
   // Small blocks: the launch has a floor of ~20 us (one 157 KB workgroup per CU, a panel load, a barrier) where the per-tile
@@ -514,7 +596,7 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
 
 int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                           int64_t n, int64_t row0, int64_t n_local, int64_t ld_dist, bool symmetric, hipStream_t stream,
-                          SpecState* spec, u64* spec_buf) {
+                          SpecState* spec, u64* spec_buf, u64* hist0) {
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
   const float* two_s = reinterpret_cast<const float*>(planes + L.x3_sc) + 4 * L.x3_dc + 1;
   const int ntk = (int)(L.x3_dk / 32);
@@ -527,7 +609,7 @@ int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, c
     ncu = v > 0 ? v : 256;
   }
   const int np = stein_x3_kind(dtype);
-#define DP_LAUNCH(KERNEL, SYM, NP) hipLaunchKernelGGL((KERNEL<SYM, NP>), dim3((unsigned)ncu), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf)
+#define DP_LAUNCH(KERNEL, SYM, NP) hipLaunchKernelGGL((KERNEL<SYM, NP>), dim3((unsigned)ncu), dim3(DP_THREADS), 0, stream, T3, ntk, r_all, dist_out, (int)row0, tiles_m, tiles_n, (long)ld_dist, two_s, spec, spec_buf, hist0)
   if (np * ntk <= 16) {
     if (np == 1) { if (symmetric) DP_LAUNCH(k_distance_panel, true, 1); else DP_LAUNCH(k_distance_panel, false, 1); }
     else { if (symmetric) DP_LAUNCH(k_distance_panel, true, 2); else DP_LAUNCH(k_distance_panel, false, 2); }

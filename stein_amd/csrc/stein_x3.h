@@ -16,7 +16,7 @@ bool stein_dpanel_ok(const SteinLayout& L, int dtype, int64_t n, int64_t row0, i
                      bool any_size);
 int stein_dpanel_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                           int64_t n, int64_t row0, int64_t n_local, int64_t ld_dist, bool symmetric, hipStream_t stream,
-                          SpecState* spec, u64* spec_buf);
+                          SpecState* spec, u64* spec_buf, u64* hist0);
 int stein_x3_contract_partial(const float* dist, int64_t ld_dist, const char* planes, const SteinLayout& L, int dtype,
                               const float* h2_dev, float* OG, float* OT, float* RS, int64_t n, int64_t d,
                               int64_t n_local, hipStream_t stream, bool upper /* dist holds only the tiles on and above

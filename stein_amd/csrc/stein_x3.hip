@@ -944,7 +944,7 @@ int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const
   (void)d;
   if (panel >= 0 && stein_dpanel_ok(L, dtype, n, row0, n_local, hist0 != nullptr && spec == nullptr, panel > 0))
     return stein_dpanel_distance(planes, L, dtype, r_all, dist_out, n, row0, n_local, ld_dist, symmetric, stream, spec,
-                                 spec_buf);
+                                 spec_buf, hist0);
   const u16* T3 = reinterpret_cast<const u16*>(planes + L.x3_t3);
   const float* two_s = reinterpret_cast<const float*>(planes + L.x3_sc) + 4 * L.x3_dc + 1;
   const int ntk = (int)(L.x3_dk / 32);

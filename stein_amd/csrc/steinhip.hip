@@ -252,15 +252,12 @@ __device__ __forceinline__ ChainState chain_resolve(const u64* hist_all, int lev
 // SYM (square symmetric block): only columns >= row are read; an off-diagonal entry counts twice.
 // Level 0 sees every value and a handful of bins hold them all -> wave-merged adds.  Levels 1-2 only see the
 // values inside the selected bin, spread over up to 2048 digits -> plain LDS atomics are cheaper.
-// CHAIN: `hist` points at level 0 of ALL levels and the block resolves the earlier levels itself (chain_resolve);
-// otherwise `hist` is this level's histogram and *st holds the state left by k_resolve.
-// fin.done != NULL (last level of the chained select): the last workgroup to finish also resolves all levels, writes the
-// median / bandwidth and updates the window predictor.
+// k_hist (staged calls): `hist` is this level's histogram and *st holds the state left by k_resolve.
+// k_hist_all (fused call): all levels in one launch; what its last resolver needs to finish the select:
 struct HistFinal {
   SelState* st;
   SpecState* sp;
   float* h2_out;
-  u32* done;
   float ln_n;
 };
 __device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out);   // below
@@ -276,21 +273,39 @@ __device__ __forceinline__ void hist_pass_body(const float* __restrict__ D, long
   // changed nothing at C2 or C3: the pass is not bound by the latency of its loads.)
   const long ntc = ldD >> 5;
   const int ntr = (n_local + DT_ROWS - 1) / DT_ROWS, ncol_tiles = (n + DT_COLS - 1) / DT_COLS;
-  const long units = (long)ntr * ncol_tiles;
+  // SYM: row tile ti only has the units tj >= 4 ti (the others lie wholly below the diagonal).  Enumerated row by row over
+  // ALL units and skipped, the strided shares were as uneven as they can be: with nvb a multiple of ncol_tiles every share
+  // keeps ONE tj -- the share of the last column strip had 32 units at C3, that of the first none, and the launch lasted as
+  // long as the longest (round 3: 0.19 ms per pass, twice the balanced time).  So the rows are folded as in the distance
+  // pass: virtual row v = row v, then row ntr - 1 - v: W = 2 ncol_tiles - 4 (ntr - 1) useful units whatever v (the middle
+  // row of an odd ntr stands alone), and L = v W + x runs over useful units only.
+  const int vrows = SYM ? (ntr + 1) / 2 : ntr;
+  const int W = SYM ? 2 * ncol_tiles - 4 * (ntr - 1) : ncol_tiles;
+  const long units = (long)vrows * W;
   for (long u = vb; u < units; u += nvb) {
-    const int ti = (int)(u / ncol_tiles), tj = (int)(u - (long)ti * ncol_tiles);
-    if (SYM && tj * DT_COLS + DT_COLS <= ti * DT_ROWS) continue;
+    int ti, tj;
+    if (SYM) {
+      const int v = (int)(u / W), x = (int)(u - (long)v * W), len0 = ncol_tiles - 4 * v;
+      if (x < len0) { ti = v; tj = 4 * v + x; }
+      else {
+        ti = ntr - 1 - v;
+        if (ti == v) continue;                       // the middle row has no partner
+        tj = 4 * ti + (x - len0);
+      }
+      if (tj >= ncol_tiles) continue;                // (cannot happen: len0 + the partner's length = W)
+    } else {
+      ti = (int)(u / ncol_tiles); tj = (int)(u - (long)ti * ncol_tiles);
+    }
     const float* tile = D + ((size_t)ti * ntc + tj) * DT_ELEMS;
     float4 v4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const float4*>(tile + (threadIdx.x + 256 * q) * 4);
     // Interior unit: every entry exists and (SYM) lies strictly above the diagonal -- no per-entry bounds, no per-entry
-    // weight.  All but the O(n / 32) units along the edges and the diagonal take this path; with the per-entry tests in
-    // front of every count the pass ran at 2.5 TB/s, bound by its own instruction count (round 3: 37 instructions per entry).
+    // weight.  All but the O(n / 32) units along the edges and the diagonal take this path (C3, three passes: 0.64 -> 0.57 ms).
     const bool interior = ti * DT_ROWS + DT_ROWS <= n_local && tj * DT_COLS + DT_COLS <= n &&
                           (!SYM || tj * DT_COLS >= ti * DT_ROWS + DT_ROWS);
     if (interior) {
-      constexpr u32 W = SYM ? 2u : 1u;
+      constexpr u32 WT = SYM ? 2u : 1u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float x[4] = {v4[q].x, v4[q].y, v4[q].z, v4[q].w};
@@ -298,12 +313,12 @@ __device__ __forceinline__ void hist_pass_body(const float* __restrict__ D, long
         for (int e = 0; e < 4; ++e) {
           const u32 key = f32_key(x[e]);
           if (LEVEL == 0) {
-            hist_add(h, key >> 21, true, lane, W);
+            hist_add(h, key >> 21, true, lane, WT);
           } else {
             const u32 digit = LEVEL == 1 ? ((key >> 10) & 2047u) : (key & 1023u);
             const u32 hi = LEVEL == 1 ? (key >> 21) : (key >> 10);
-            if (hi == pa) atomicAdd(&h[digit], W);
-            if (two && hi == pb) atomicAdd(&h[STEIN_HIST_BINS + digit], W);
+            if (hi == pa) atomicAdd(&h[digit], WT);
+            if (two && hi == pb) atomicAdd(&h[STEIN_HIST_BINS + digit], WT);
           }
         }
       }
@@ -338,38 +353,24 @@ __device__ __forceinline__ void hist_pass_body(const float* __restrict__ D, long
   }
 }
 
-template <int LEVEL, bool SYM, bool CHAIN = false>
+template <int LEVEL, bool SYM>
 __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long ldD, int n_local, int n,
-                                              const SelState* st, u64* hist, const u32* __restrict__ skip,
-                                              HistFinal fin) {
+                                              const SelState* st, u64* hist, const u32* __restrict__ skip) {
   if (skip && *skip) return;   // the speculative window already produced this step's median
-  u64* const hist_all = hist;
   __shared__ u32 h[2 * STEIN_HIST_BINS];
   for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
   __syncthreads();
-
-  u32 pa, pb;
-  bool two;
-  if (CHAIN) {
-    const ChainState cs = chain_resolve<false>(hist, LEVEL, st);
-    pa = cs.prefix[0]; pb = cs.prefix[1]; two = cs.two;
-    hist += (size_t)LEVEL * 2 * STEIN_HIST_BINS;
-  } else {
-    pa = st->prefix[0]; pb = st->prefix[1];
-    two = st->diverged != 0u;
-  }
+  const u32 pa = st->prefix[0], pb = st->prefix[1];
+  const bool two = st->diverged != 0u;
   hist_pass_body<LEVEL, SYM>(D, ldD, n_local, n, h, pa, pb, two, blockIdx.x, gridDim.x);
   __syncthreads();
-  for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256)
+  for (int b = threadIdx.x; b < (two ? 2 : 1) * STEIN_HIST_BINS; b += 256)
     if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
-  if (CHAIN && LEVEL == STEIN_HIST_LEVELS - 1) {
-    if (fin.done && last_workgroup_out(fin.done, gridDim.x)) resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
-  }
 }
 
-// The whole chained radix select of the fused symmetric call in ONE launch, for blocks small enough that the launches
-// themselves were the cost (n <= HIST_ALL_MAX_N: when the window hit -- the usual case -- three launches returned at once,
-// a few microseconds each).  The workgroups of the one launch meet behind each level.
+// The whole chained radix select of the fused symmetric call in ONE launch (round 3: for n <= 4096 only, three chained
+// launches above that; round 4: every size -- when the window hit, the usual case, three launches returned at once, a few
+// microseconds each).  The workgroups of the one launch meet behind each level.
 //
 // No workgroup ever waits for one that has not started (round 3's form assumed that the whole grid was resident: two
 // processes on a card, or a stream with a CU mask, could leave the resident workgroups spinning for absent ones).  The work
@@ -386,10 +387,10 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
 // The wait is bounded all the same (a hardware fault is the only way to exhaust it): FuseState::gave_up turns the
 // step's bandwidth into NaN -- a wrong median is never returned -- and raises the device's error word in page-locked host
 // memory, which the next call of the C ABI on this device reports as STEIN_E_HIP (stein_take_device_error).
-constexpr int HIST_ALL_MAX_N = 4096;
 constexpr int HIST_SPIN_MAX = 1 << 22;
 constexpr int HIST_BLOCKS = 2048;      // workgroups of a histogram pass (C3, every step a miss: 0.61 ms of select with 2048, 0.77 with 1024, 1.17 with 512)
-constexpr int HIST_ALL_VBLOCKS = 512;  // virtual workgroups of k_hist_all = its grid, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
+constexpr int HIST_ALL_SMALL_N = 4096; // up to here k_hist_all runs HIST_ALL_VBLOCKS virtual workgroups, above HIST_BLOCKS
+constexpr int HIST_ALL_VBLOCKS = 512;  // ... = its grid, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
 __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, long ldD, int n, const SelState* st, u64* hist_all,
                                                   const u32* __restrict__ hit, const u32* __restrict__ skip_l0, HistFinal fin,
                                                   FuseState* fs /* draw[], done[], gen, pub[] zero at launch */, u32 nvb,
@@ -441,9 +442,9 @@ __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, l
     if (last) {
       cs = chain_resolve<true>(hist_all, level + 1, st);
       if (threadIdx.x == 0) {
-        const u32 w[4] = {cs.prefix[0], cs.prefix[1], (u32)cs.rank[0], (u32)cs.rank[1]};
+        const u32 w[6] = {cs.prefix[0], cs.prefix[1], (u32)cs.rank[0], (u32)(cs.rank[0] >> 32), (u32)cs.rank[1], (u32)(cs.rank[1] >> 32)};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) __hip_atomic_store(&fs->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(&fs->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&fs->gen, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -457,11 +458,11 @@ __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, l
     __syncthreads();
     // (a workgroup that started late may read the state of a LATER level here, or a mix of two: then that later level was
     // complete before the read, its draw counter is exhausted, and the state is never used)
-    u32 w[4];
+    u32 w[6];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = load_fresh(&fs->pub[k]);
+    for (int k = 0; k < 6; ++k) w[k] = load_fresh(&fs->pub[k]);
     cs.prefix[0] = w[0]; cs.prefix[1] = w[1];
-    cs.rank[0] = (u64)w[2]; cs.rank[1] = (u64)w[3];
+    cs.rank[0] = (u64)w[2] | ((u64)w[3] << 32); cs.rank[1] = (u64)w[4] | ((u64)w[5] << 32);
     cs.two = w[0] != w[1];
   }
 }
@@ -1370,34 +1371,29 @@ extern "C" int stein_median_begin(void* hist, void* select_state, int64_t total,
 }
 
 template <int LEVEL>
-static void launch_hist(bool sym, bool chain, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
-                        const SelState* st, u64* h, const u32* skip, const HistFinal& fin) {
-  if (sym && chain)
-    hipLaunchKernelGGL((k_hist<LEVEL, true, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip, fin);
-  else if (sym)
-    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip, fin);
+static void launch_hist(bool sym, int blocks, hipStream_t s, const float* dist, long ld, int n_local, int n,
+                        const SelState* st, u64* h, const u32* skip) {
+  if (sym)
+    hipLaunchKernelGGL((k_hist<LEVEL, true>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
   else
-    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip, fin);
+    hipLaunchKernelGGL((k_hist<LEVEL, false>), dim3(blocks), dim3(256), 0, s, dist, ld, n_local, n, st, h, skip);
 }
 
-// chain (fused symmetric call only): the pass resolves the earlier levels itself, `hist` is the base of all levels
 static int hist_pass_impl(const float* dist, int64_t ld_dist, int64_t n_local, int64_t n, int level,
-                          const void* select_state, void* hist, int flags, void* stream, const u32* skip,
-                          bool chain = false, const HistFinal& fin = HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f}) {
+                          const void* select_state, void* hist, int flags, void* stream, const u32* skip) {
   if (!dist || !select_state || !hist) return fail(STEIN_E_BADARG, "NULL pointer");
   if (level < 0 || level >= STEIN_HIST_LEVELS) return fail(STEIN_E_BADARG, "level %d", level);
   if (ld_dist < n || (ld_dist & 31) || n_local < 1) return fail(STEIN_E_SHAPE, "bad distance block shape (ld_dist must be a multiple of 32)");
   const bool sym = (flags & STEIN_STAGE_SYMMETRIC) != 0;
   if (sym && n_local != n) return fail(STEIN_E_BADARG, "STEIN_STAGE_SYMMETRIC needs a square block");
-  if (chain && !sym) return fail(STEIN_E_BADARG, "the chained select is the fused symmetric call's");
   const long units = ((n_local + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);   // [128][32] tiles
   const int blocks = (int)(units < HIST_BLOCKS ? units : HIST_BLOCKS);
-  u64* h = (u64*)hist + (chain ? 0 : (size_t)level * 2 * STEIN_HIST_BINS);
+  u64* h = (u64*)hist + (size_t)level * 2 * STEIN_HIST_BINS;
   const SelState* st = (const SelState*)select_state;
   hipStream_t s = (hipStream_t)stream;
-  if (level == 0) launch_hist<0>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip, fin);
-  else if (level == 1) launch_hist<1>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip, fin);
-  else launch_hist<2>(sym, chain, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip, fin);
+  if (level == 0) launch_hist<0>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  else if (level == 1) launch_hist<1>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
+  else launch_hist<2>(sym, blocks, s, dist, (long)ld_dist, (int)n_local, (int)n, st, h, skip);
   LAUNCH_CHECK("k_hist");
   return STEIN_OK;
 }
@@ -1823,10 +1819,10 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     return STEIN_OK;
   }
   // The prologue carries the row norms and all set-up; kernels let their last workgroup do what a one-workgroup follow-up
-  // launch would (FuseState tickets: scales, final resolve, |phi|^2 sum); the chained radix select is one launch for
-  // n <= HIST_ALL_MAX_N and none for n <= SOLO_MAX_N (k_spec_select covers it); bf16 inputs need no scales, so their
-  // prologue rides in the split's launch.  fp32 inputs: k_prologue, k_colmax, k_split, distance, k_spec_select, select
-  // (0 / 1 / 3 launches), contraction, k_phi_finish (+ k_sum_partials beyond 512 workgroups); bf16 at C2's size: six.
+  // launch would (FuseState tickets: scales, |phi|^2 sum); the chained radix select is ONE launch (k_hist_all) and none
+  // for n <= SOLO_MAX_N (k_spec_select covers it); bf16 inputs need no scales, so their prologue rides in the split's
+  // launch.  fp32 inputs: k_prologue, k_colmax, k_split, distance, k_spec_select, k_hist_all, contraction, k_phi_finish
+  // (+ k_sum_partials beyond 512 workgroups): eight or nine launches whatever n; bf16 at C2's size: six.
   FuseState* fuse = (FuseState*)((char*)sel + sizeof(SelState) + sizeof(SpecState));
   {
     u32* cmax = nullptr;
@@ -1869,12 +1865,14 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
                      (float)log((double)n), h2_out, 1, solo ? (const float*)D : (const float*)nullptr, (long)L.ld_dist,
                      (int)n);
   LAUNCH_CHECK("k_spec_select");
-  // chained radix select: three passes that resolve the earlier levels themselves; the last workgroup of the third
-  // resolves the rest.  Level 0 comes from the distance epilogue unless this step had a window (then only a miss needs it).
-  const HistFinal fin{(SelState*)sel, spec, h2_out, &fuse->done_hist, (float)log((double)n)};
-  if (!solo && n <= HIST_ALL_MAX_N) {   // one launch for all three levels (k_hist_all: in-launch level barriers that need no co-residency)
+  // chained radix select, ONE launch whatever n (k_hist_all: in-launch level barriers that need no co-residency; it returns
+  // at once when the window hit).  Level 0 comes from the distance epilogue unless this step had a window (then only a
+  // miss needs it, and the launch takes it itself: SpecState::skip_l0).
+  if (!solo) {
+    const HistFinal fin{(SelState*)sel, spec, h2_out, (float)log((double)n)};
     const long units = ((n + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);
-    const int nvb = (int)(units < HIST_ALL_VBLOCKS ? units : HIST_ALL_VBLOCKS);
+    const long want = n <= HIST_ALL_SMALL_N ? HIST_ALL_VBLOCKS : HIST_BLOCKS;
+    const int nvb = (int)(units < want ? units : want);
     const int blocks = g_hist_all_grid > 0 ? g_hist_all_grid : nvb;   // (test hook: any grid >= 1 must give the same median)
     u32* errword = nullptr;
     if ((rc = device_error_word(&errword))) return rc;
@@ -1882,11 +1880,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
                        (const SelState*)sel, (u64*)hist, (const u32*)&spec->hit, (const u32*)&spec->skip_l0, fin, fuse,
                        (u32)nvb, errword);
     LAUNCH_CHECK("k_hist_all");
-  } else
-  for (int lv = 0; lv < (solo ? 0 : STEIN_HIST_LEVELS); ++lv)
-    if ((rc = hist_pass_impl(D, L.ld_dist, n_local, n, lv, sel, hist, sf, stream, lv == 0 ? &spec->skip_l0 : &spec->hit,
-                             true, lv == STEIN_HIST_LEVELS - 1 ? fin : HistFinal{nullptr, nullptr, nullptr, nullptr, 0.f})))
-      return rc;
+  }
   // the split path's symmetric distance pass stores only the tiles on and above the diagonal
   const int df = planes ? (STEIN_STAGE_SYMMETRIC | STEIN_STAGE_UPPER) : STEIN_STAGE_SYMMETRIC;
   if (K_out && (rc = stein_kernel_matrix(D, L.ld_dist, n_local, n, h2_out, K_out, n, df, stream))) return rc;

@@ -201,18 +201,41 @@ class AbstractSteinSampler:
         theta_array += self.gd.update(phi)                                   # :126
         self.theta_matrix.copy_(torch.as_tensor(theta_array).to(self.theta_matrix))   # :127
 
-    def function_posterior(self, func, feed_dict=None, axis=None):
+    def function_posterior(self, func, feed_dict=None, axis=None, gather=True):
         """Evaluate `func` under every particle (abstract_stein_sampler.py:157-168).
 
         func(theta_dict_or_matrix, feed_dict) must be batched over particles and return [n_local, ...]; the
-        result is flattened per particle to [n_local, out] like the reference's np.ravel, and averaged over
-        `axis` when given.  Returns NumPy.
+        result is flattened per particle to [n_local, out] like the reference's np.ravel.  Sharded sampler: every rank
+        evaluates its own particles and the rows are all-gathered in rank order (rank p holds particles
+        [p n/P, (p + 1) n/P), so the gathered array is indexed like the reference's, all n particles: :160-162), unless
+        gather=False.  The mean over `axis` is taken of that [n, out] array, as the reference does (:165-168).  Returns
+        NumPy, the same array on every rank.  Collective when sharded: every rank must call it.
         """
         arg = self.theta if self._access is not None else self.theta_matrix
         with torch.no_grad():
             out = func(arg, feed_dict)
-        out = torch.as_tensor(out).reshape(self.n_local, -1).detach().cpu().numpy()
+        out = torch.as_tensor(out).reshape(self.n_local, -1).detach()
+        if self._group is not None and gather:
+            import torch.distributed as dist
+            world = dist.get_world_size(self._group)
+            # (the per-particle output width is the same on every rank: the same func on the same shapes)
+            mine = out.to(self.device).contiguous()
+            full = torch.empty(world * self.n_local, mine.shape[1], dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(full, mine, group=self._group)
+            out = full
+        out = out.cpu().numpy()
         return out.mean(axis=axis) if axis is not None else out
+
+    def samples_all(self):
+        """All n particles as one float64 [n, d] NumPy array on every rank (the reference's `samples`, stein_sampler.py:73-78,
+        for a sharded sampler; on one rank it equals `samples`).  Collective when sharded."""
+        if self._group is None:
+            return self.theta_matrix.detach().double().cpu().numpy()
+        import torch.distributed as dist
+        world = dist.get_world_size(self._group)
+        full = torch.empty(world * self.n_local, self.n_params, dtype=self.theta_matrix.dtype, device=self.device)
+        dist.all_gather_into_tensor(full, self.theta_matrix.contiguous(), group=self._group)
+        return full.double().cpu().numpy()
 
     @abstractmethod
     def train_on_batch(self, batch_feed):

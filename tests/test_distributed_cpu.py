@@ -222,3 +222,55 @@ def test_comm_argument_is_validated(tmp_path):
         assert comm == "torch"
         assert "comm='native' needs" in msg
         assert "comm must be" in bad
+
+
+def _posterior_func(theta, feed):
+    """batched over particles: per particle the vector of sigmoid(x . w + b) over the feed's points (the logistic example's
+    `evaluate`-style readout, examples/logistic_regression/main.py:52-61)"""
+    w, b = theta["model/w:0"], theta["model/b:0"]                 # [m, 3, 1], [m]
+    X = torch.as_tensor(feed["X"], dtype=w.dtype)
+    return torch.sigmoid(torch.einsum("pf,mfo->mp", X, w) + b[:, None])
+
+
+def _worker_posterior(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stein_amd.samplers import SteinSampler
+        from stein_amd.optimizers import AdamGradientDescent
+        s = SteinSampler(n, None, AdamGradientDescent(0.1), theta=None, model_vars={"model/w:0": [3, 1], "model/b:0": []},
+                         device="cpu", group=dist.group.WORLD, seed=11, dtype=torch.float64)
+        X = np.random.default_rng(3).normal(size=(5, 3))
+        full = s.function_posterior(_posterior_func, {"X": X})
+        mean0 = s.function_posterior(_posterior_func, {"X": X}, axis=0)
+        local = s.function_posterior(_posterior_func, {"X": X}, gather=False)
+        np.savez(os.path.join(out_dir, "post%d.npz" % rank), full=full, mean0=mean0, local=local, samples=s.samples_all())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_function_posterior_gathers_all_particles_on_a_sharded_sampler(tmp_path):
+    """abstract_stein_sampler.py:157-168 returns one row per particle for ALL n particles (and the mean over them with
+    `axis`); a sharded sampler evaluates its own rows and all-gathers them in rank order.  Checked against the reference's
+    per-particle loop (NumPy, one particle at a time, np.ravel of each output) over the single-rank draw of the same seed."""
+    world, n = 2, 12
+    mp.spawn(_worker_posterior, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    from stein_amd.samplers import SteinSampler
+    from stein_amd.optimizers import AdamGradientDescent
+    one = SteinSampler(n, None, AdamGradientDescent(0.1), theta=None, model_vars={"model/w:0": [3, 1], "model/b:0": []},
+                       device="cpu", seed=11, dtype=torch.float64)
+    X = np.random.default_rng(3).normal(size=(5, 3))
+    th = {v: t.numpy() for v, t in one.theta.items()}
+    rows = []
+    for i in range(n):                                            # the reference's loop, :160-162
+        w, b = th["model/w:0"][i], th["model/b:0"][i]
+        rows.append(np.ravel(1.0 / (1.0 + np.exp(-(X @ w + b)))))
+    want = np.array(rows)
+    assert want.shape == (n, 5)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "post%d.npz" % r))
+        assert got["full"].shape == (n, 5) and np.allclose(got["full"], want, rtol=1e-12, atol=0)
+        assert np.allclose(got["mean0"], want.mean(axis=0), rtol=1e-12, atol=0)
+        assert np.allclose(got["local"], want[r * (n // world):(r + 1) * (n // world)], rtol=1e-12, atol=0)
+        assert np.array_equal(got["samples"], one.theta_matrix.numpy())

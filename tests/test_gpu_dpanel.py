@@ -185,3 +185,47 @@ def test_panel_kernels_are_deterministic_under_memory_pressure(cuda, n, d, dtype
         torch.cuda.synchronize()
         same = (eng.dist == first) | (eng.dist.isnan() & first.isnan())
         assert bool(same.all()), "repetition %d differs in %d entries" % (rep, int((~same).sum()))
+
+
+def _level0_counts(M, sym):
+    """level-0 digits (top 11 bits of the order-preserving key, stein_common.h: f32_key) of a row-major distance matrix"""
+    bits = M.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+    key = torch.where(bits >= (1 << 31), (~bits) & 0xffffffff, bits | (1 << 31))
+    return torch.bincount((key >> 21).flatten(), minlength=_lib.HIST_BINS)
+
+
+@pytest.mark.parametrize("n,d,sym,row0,nl,spread", [(1024, 64, True, 0, 1024, False), (1024, 64, False, 256, 512, False),
+                                                    (768, 320, True, 0, 768, False), (640, 700, False, 128, 384, False),
+                                                    (1024, 48, True, 0, 1024, True), (1024, 16, False, 0, 512, True)])
+def test_panel_epilogue_takes_the_level0_histogram(cuda, n, d, sym, row0, nl, spread):
+    """A step without a window: the panel kernels (d <= 256: k_distance_panel, beyond: k_distance_panel_deep) count the
+    level-0 radix-select digits in their epilogue (per-lane 8-bit slots around the wave's first digit, LDS histogram per
+    workgroup).  The histogram must equal a direct count over the kernel's own distance image -- also when the distances
+    span many digits (`spread`: particle scales from 1e-3 to 1e3, so most entries miss the slots and take the direct path) and
+    when a few of them are negative (identical particles: r_i + r_j - 2 <t_i, t_j> cancels to +-tiny)."""
+    T, G = _inputs(n, d, cuda, seed=13)
+    if spread:
+        T = T * torch.logspace(-3, 3, n, device=cuda)[:, None]
+        T[5] = T[4]; T[n - 2] = T[n - 1]                                # coincident pairs: distances around +-0
+    st = SvgdEngine(8, 2, device=cuda).stages
+    total, offs, extra = st.workspace_layout(nl, n, d, _lib.FLAG_X3)
+    ws = torch.zeros(total, dtype=torch.uint8, device=cuda)
+    ld = extra[_lib.WSX_LD_DIST]
+    r = ws[offs[_lib.WS_ROWNORM]:offs[_lib.WS_ROWNORM] + 4 * n].view(torch.float32)
+    D = ws[offs[_lib.WS_DIST]:offs[_lib.WS_DIST] + nl * ld * 4].view(torch.float32).view(nl, ld)
+    hist = ws[offs[_lib.WS_HIST]:offs[_lib.WS_HIST] + _lib.HIST_LEVELS * 2 * _lib.HIST_BINS * 8].view(torch.int64)
+    hist = hist.view(_lib.HIST_LEVELS, 2, _lib.HIST_BINS)
+    sel = ws[offs[_lib.WS_SELECT]:offs[_lib.WS_SELECT] + 128]
+    planes = ws[offs[_lib.WS_PLANES]:total]
+    st.rownorms(T, n, d, r)
+    st.x3_prepare(T, G, n, d, planes)
+    for name, kernel in (("tiles", _lib.STAGE_TILES), ("panel", _lib.STAGE_PANEL)):
+        st.median_begin(hist, sel, n * n)
+        st.distance_block(T, r, n, d, row0, nl, D, ld, hist0=hist[0], symmetric=sym, planes=planes, kernel=kernel)
+        torch.cuda.synchronize()
+        M = untile_distances(D, nl, n, upper=sym)
+        want = _level0_counts(M, sym)
+        got = hist[0, 0]
+        assert int(got.sum()) == nl * n, (name, int(got.sum()))
+        assert torch.equal(got, want), (name, (got - want).nonzero().flatten().tolist()[:8])
+        assert int(hist[0, 1].abs().sum()) == 0 and int(hist[1:].abs().sum()) == 0

@@ -128,9 +128,9 @@ def test_last_workgroup_tickets_match_separate_launches(cuda, seed):
 
 
 @pytest.mark.parametrize("n,d,dtype", [(513, 5, torch.float32), (1000, 33, torch.float32), (2049, 64, torch.bfloat16),
-                                        (4096, 128, torch.bfloat16), (4224, 9, torch.float32)])   # (the last: just above -- three launches)
+                                        (4096, 128, torch.bfloat16), (4224, 9, torch.float32)])   # (the last: 2048 virtual workgroups)
 def test_one_launch_select_without_the_window(cuda, n, d, dtype):
-    """window=False, 512 < n <= 4096: every step takes the one-launch chained radix select (k_hist_all: all levels in one
+    """window=False, n > 512: every step takes the one-launch chained radix select (k_hist_all: all levels in one
     launch, workgroups meeting at in-launch barriers, the last arrival resolving a level for all of them; the level-0 counts
     come from the distance kernel or, with skip_l0 clear, from the launch itself).  Bandwidth, phi and |phi|^2 equal the
     staged calls' (separate k_hist / k_resolve launches) bit for bit at every step, for odd and even n^2."""
@@ -149,14 +149,14 @@ def test_one_launch_select_without_the_window(cuda, n, d, dtype):
         assert _spec_state(fused)["hit"] == 0
 
 
-@pytest.mark.parametrize("grid", [1, 3, 40, 4096])
-def test_one_launch_select_needs_no_co_residency(cuda, grid):
+@pytest.mark.parametrize("grid,n", [(1, 2304), (3, 2304), (40, 2304), (4096, 2304), (7, 4608), (3000, 4608)])
+def test_one_launch_select_needs_no_co_residency(cuda, grid, n):
     """k_hist_all's level barriers never wait for a workgroup that has not started: the work of a level is cut into 512
     virtual workgroups that the running workgroups DRAW (FuseState::draw / done / gen).  Forced here: the launch gets 1, 3
     or 40 workgroups (far fewer than the 512 virtual ones: the few present take them all over) or 4096 (more than the chip
     holds at once: the late ones find every counter exhausted and fall through).  The median -- hence bandwidth, phi and
     |phi|^2 -- equals the staged calls' bit for bit every time, and no error is raised."""
-    n, d = 2304, 24                                                  # 18 x 72 = 1296 units of [128][32]
+    d = 24                                                           # n = 2304: 512 virtual workgroups; 4608: 2048
     g = torch.Generator(device="cpu").manual_seed(grid)
     fused = SvgdEngine(n, d, device=cuda, window=False, small=False)
     staged = SvgdEngine(n, d, device=cuda, small=False)
