@@ -372,6 +372,7 @@ int stein_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* str
  * stein_debug_raise_device_error raises the current device's word as a kernel would. */
 int stein_take_device_error(void);
 int stein_debug_hist_all_grid(int blocks);
+int stein_debug_hist_all_vblocks(int nvb);   /* tuning aid: virtual workgroups per level of that kernel (0 = default) */
 int stein_debug_raise_device_error(void);
 
 #ifdef __cplusplus

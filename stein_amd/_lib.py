@@ -80,6 +80,7 @@ _SIGNATURES = {
     "stein_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "stein_take_device_error": [],
     "stein_debug_hist_all_grid": [_int],
+    "stein_debug_hist_all_vblocks": [_int],
     "stein_debug_raise_device_error": [],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["stein_version", "stein_last_error"])

@@ -136,16 +136,26 @@ static_assert(sizeof(SpecState) == 64, "SpecState must stay 64 bytes");
 // kernel; each ticket also resets itself.
 struct FuseState {
   u32 done_colmax, done_finish;
-  // k_hist_all (the chained select in one launch, steinhip.hip).  The work of a level is cut into G "virtual workgroups";
-  // whichever real workgroups are running DRAW them from draw[level], so a level completes with any number of resident
-  // workgroups and nobody ever waits for a workgroup that has not started.
-  u32 draw[3];     // next virtual workgroup of each level
-  u32 done[3];     // virtual workgroups of each level whose counts have reached the global histogram
-  u32 gen;         // levels resolved and published since the launch
-  u32 pub[6];      // the select state the resolver published: prefix[2], rank[2] as halves
-  u32 gave_up;     // a bounded wait ran out (cannot happen by construction; the bandwidth becomes NaN and the host is told)
+  u32 gave_up;     // k_hist_all: a bounded wait ran out (cannot happen by construction; the bandwidth becomes NaN and the host is told)
+  u32 pad[13];
 };
 static_assert(sizeof(FuseState) == 64, "FuseState must stay 64 bytes");
+// Synchronisation state of k_hist_all (the fused call's chained radix select in one launch, steinhip.hip): lives in the
+// rank-summed window table of the SPEC section, which a single-rank fused call has no other use for; zeroed by the fused
+// call's first kernel.  Laid out so that NO address is hit by more than a few dozen workgroups: a device-scope atomic that
+// returns its value costs ~20 ns when two thousand workgroups aim it at one address (they are performed one after the
+// other at the memory side), which made round 4's first form -- one draw counter, one arrival counter, one flag -- spend
+// as long on its barriers as on its passes at C3 (470 us for levels 1 + 2 against 240 us as two launches).
+constexpr int HS_NV = 2048;       // virtual workgroups per level, at most
+constexpr int HS_CLASSES = 64;    // virtual workgroup v reports to / listens on class v % 64
+struct HistSync {
+  u32 claim[STEIN_HIST_LEVELS][HS_NV];     // virtual workgroup v of a level has been taken (by its owner, or by a thief)
+  struct Leaf { u32 done; u32 pad[15]; } leaf[STEIN_HIST_LEVELS][HS_CLASSES];   // finished virtual workgroups of a class
+  struct Top { u32 classes; u32 pad[15]; } top[STEIN_HIST_LEVELS];               // classes that are complete
+  struct Line { u32 gen; u32 pub[6]; u32 pad[9]; } line[HS_CLASSES];   // per class: levels published so far + the select
+                                                                       // state the resolver published (prefix[2], rank[2] as halves)
+};
+static_assert(sizeof(HistSync) % 8 == 0, "HistSync is carved out of a u64 table");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;
 constexpr u32 SPEC_QCAP = 1016;          // per-workgroup LDS queue (entries of 8 bytes; shares its LDS with the histogram)
 constexpr u32 SPEC_CAP = (1u << 21) - 2048u;   // global buffer capacity (entries); the 16 MB section starts with
@@ -609,6 +619,7 @@ struct PrologueArgs {
   u32* cmax; int ncmax;
   int allow_window;
   float* neutral_sc; int dc;
+  u32* hsync; int hsync_words;   // HistSync of k_hist_all (zeroed here)
 };
 constexpr int PRO_INIT_BLOCKS = 16;   // (k_prologue's grid: one workgroup per four rows + these; any grid works)
 __device__ __forceinline__ float prologue_elem(const float* p) { return *p; }
@@ -622,6 +633,7 @@ __device__ __forceinline__ void prologue_body(const TIN* __restrict__ T, const P
     if (gt == 0) { a.neutral_sc[4 * a.dc] = 1.f; a.neutral_sc[4 * a.dc + 1] = 2.f; a.neutral_sc[4 * a.dc + 2] = 1.f; }
   }
   if (gt < 16) reinterpret_cast<u32*>(a.fs)[gt] = 0u;
+  for (int i = gt; i < a.hsync_words; i += gn) a.hsync[i] = 0u;
   median_init_body(gt, gn, a.st, a.sp, a.total, a.hist, a.slots, a.allow_window);
   const int lane = threadIdx.x & 63;
   for (int row = gt >> 6; row < a.n; row += gn >> 6) {

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_distance(const float* __restric
 // the same 16 KB with device-scope loads queued on the handful of memory channels that hold it, ~50 us per pass at C2).
 struct ChainState { u32 prefix[2]; u64 rank[2]; bool two; };
 template <bool FRESH>
-__device__ __forceinline__ ChainState chain_resolve(const u64* hist_all, int levels, const SelState* st) {
+__device__ __attribute__((noinline)) ChainState chain_resolve(const u64* hist_all, int levels, const SelState* st) {
   __shared__ u64 c_part[256];
   __shared__ u32 c_bin[2];
   __shared__ u64 c_rest[2];
@@ -260,7 +260,7 @@ struct HistFinal {
   float* h2_out;
   float ln_n;
 };
-__device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out);   // below
+__device__ __attribute__((noinline)) void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out);   // below
 
 // one histogram pass of a workgroup over a share of the block (units vb, vb + nvb, ... of "virtual workgroup" vb of nvb):
 // digits of LEVEL into the LDS histogram h[2][STEIN_HIST_BINS] (zeroed by the caller), given the prefixes the earlier levels fixed
@@ -374,93 +374,172 @@ __global__ __launch_bounds__(256) void k_hist(const float* __restrict__ D, long 
 //
 // No workgroup ever waits for one that has not started (round 3's form assumed that the whole grid was resident: two
 // processes on a card, or a stream with a CU mask, could leave the resident workgroups spinning for absent ones).  The work
-// of a level is cut into G = HIST_ALL_VBLOCKS "virtual workgroups" (virtual workgroup v takes units v, v + G, ...), and the
-// REAL workgroups draw them from FuseState::draw[level] until none is left; after its last one a workgroup flushes its LDS
-// histogram into the global one (device-scope atomics, acknowledged: s_waitcnt vmcnt(0)) and adds the number of virtual
-// workgroups it took to FuseState::done[level].  The add that completes G makes its workgroup the level's resolver: it walks
-// the global histogram once (chain_resolve, device-scope loads), publishes the select state in FuseState::pub and raises
-// FuseState::gen.  The others wait for gen.  A waiting workgroup therefore only ever waits for virtual workgroups that were
-// DRAWN -- by running workgroups, which never wait before they report them done -- so every level completes with one
-// resident workgroup as well as with 512, and a workgroup that starts late finds every counter exhausted and falls through.
-// With the whole grid resident (the normal case) every workgroup draws exactly one virtual workgroup per level: the same
-// split of the work as a static one, for one extra atomic round trip per level.
+// of a level is cut into nvb "virtual workgroups" (virtual workgroup v takes units v, v + nvb, ... of hist_pass_body's
+// enumeration).  Real workgroup b takes virtual workgroup b -- after CLAIMING it (atomic exchange on HistSync::claim, an
+// address of its own) -- flushes its LDS histogram into the global one (device-scope atomics, acknowledged: s_waitcnt
+// vmcnt(0)) and reports it done: one add on its class's leaf counter, and the add that completes a class adds to the top
+// counter; the add that completes the top makes its workgroup the level's resolver: it walks the global histogram once
+// (chain_resolve, device-scope loads), publishes the select state and the new generation in all 64 class lines.  The
+// others poll the line of their class (32 pollers per line; a line carries the state too).  A workgroup that has waited
+// HIST_PATIENCE polls without seeing the level complete starts looking for UNCLAIMED virtual workgroups (their owners have not
+// started: the chip is shared, the stream has a CU mask, or the launch is larger than the chip) and takes them over, one
+// after the other, before it goes back to waiting.  So a waiting workgroup only ever waits for virtual workgroups that
+// somebody running has claimed, and every level completes with one resident workgroup as well as with two thousand; a
+// workgroup that starts late finds its own virtual workgroup taken and every level published, and falls through.
 // The wait is bounded all the same (a hardware fault is the only way to exhaust it): FuseState::gave_up turns the
 // step's bandwidth into NaN -- a wrong median is never returned -- and raises the device's error word in page-locked host
 // memory, which the next call of the C ABI on this device reports as STEIN_E_HIP (stein_take_device_error).
-constexpr int HIST_SPIN_MAX = 1 << 22;
+constexpr int HIST_SPIN_MAX = 1 << 20;
+constexpr int HIST_PATIENCE = 160;     // polls (~0.3 ms in all, hs_wait) before a waiting workgroup looks for abandoned work
 constexpr int HIST_BLOCKS = 2048;      // workgroups of a histogram pass (C3, every step a miss: 0.61 ms of select with 2048, 0.77 with 1024, 1.17 with 512)
 constexpr int HIST_ALL_SMALL_N = 4096; // up to here k_hist_all runs HIST_ALL_VBLOCKS virtual workgroups, above HIST_BLOCKS
 constexpr int HIST_ALL_VBLOCKS = 512;  // ... = its grid, 2 per CU (C2, a miss: 135 us with 512, 165 with 256, 180 with 1024)
+static_assert(sizeof(HistSync) <= (size_t)SPEC_TABLE * 8, "HistSync lives in the window table");
+static_assert(HIST_BLOCKS <= HS_NV, "HistSync::claim holds one flag per virtual workgroup");
+
+// thread 0: virtual workgroup v of `level` is done (its counts have reached the global histogram) -> is this the last one?
+__device__ __forceinline__ bool hs_report_done(HistSync* hs, int level, u32 v, u32 nvb) {
+  const u32 c = v % HS_CLASSES;
+  const u32 quota = (nvb - c + HS_CLASSES - 1) / HS_CLASSES;          // virtual workgroups of class c
+  if (__hip_atomic_fetch_add(&hs->leaf[level][c].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != quota) return false;
+  const u32 nclasses = nvb < (u32)HS_CLASSES ? nvb : (u32)HS_CLASSES;
+  return __hip_atomic_fetch_add(&hs->top[level].classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nclasses;
+}
+// whole workgroup: an unclaimed virtual workgroup of `level`, claimed for the caller; nvb if there is none.  Every thief
+// scans from a start of its own (workgroup id x a stride coprime to any nvb <= 2048, + the number of its attempt): a
+// thousand thieves that all took the FIRST unclaimed entry fought over one virtual workgroup per round (first form: 19 ms
+// for a level with 256 absent owners).
+__device__ __attribute__((noinline)) u32 hs_steal(HistSync* hs, int level, u32 nvb) {
+  __shared__ u32 s_first, s_got;
+  for (u32 attempt = 0;; ++attempt) {
+    if (threadIdx.x == 0) s_first = nvb;
+    __syncthreads();
+    const u32 start = (blockIdx.x * 1021u + attempt * 97u) % nvb;
+    u32 mine = nvb;   // position in scan order (0 = start) of this thread's first unclaimed entry
+    for (u32 i = threadIdx.x; i < nvb; i += 256) {
+      u32 v = start + i;
+      if (v >= nvb) v -= nvb;
+      if (load_fresh(&hs->claim[level][v]) == 0u) { mine = i; break; }
+    }
+    if (mine < nvb) atomicMin(&s_first, mine);
+    __syncthreads();
+    const u32 pos = s_first;
+    if (pos >= nvb) return nvb;
+    u32 cand = start + pos;
+    if (cand >= nvb) cand -= nvb;
+    if (threadIdx.x == 0)
+      s_got = __hip_atomic_exchange(&hs->claim[level][cand], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1u : 0u;
+    __syncthreads();
+    const bool got = s_got != 0u;
+    __syncthreads();   // (s_first / s_got are rewritten by the next round)
+    if (got) return cand;
+  }
+}
+
+// thread 0: poll a class line until it carries generation `want`; false when max_polls ran out.  Naps of 0.25 us at first,
+// 2 us after the first few dozen polls (a poll is a device-scope load: it goes to the memory side every time).
+__device__ __forceinline__ bool hs_wait(const u32* gen, u32 want, int max_polls) {
+  int nap = 1;
+  for (int spin = 0; spin < max_polls; ++spin) {
+    if (load_fresh(gen) >= want) return true;
+    for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(8);
+    if (spin >= 32 && nap < 8) nap += nap;
+  }
+  return false;
+}
+
+// (not inlined, one function per level: see resolve_all_body; the three passes in one function took 70 registers, 36 apart)
+template <int LEVEL>
+__device__ __attribute__((noinline)) void hist_pass_sym(const float* __restrict__ D, long ldD, int n, u32* h, u32 pa, u32 pb,
+                                                        bool two, u32 v, u32 nvb) {
+  hist_pass_body<LEVEL, true>(D, ldD, n, n, h, pa, pb, two, v, nvb);
+}
+
 __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ D, long ldD, int n, const SelState* st, u64* hist_all,
                                                   const u32* __restrict__ hit, const u32* __restrict__ skip_l0, HistFinal fin,
-                                                  FuseState* fs /* draw[], done[], gen, pub[] zero at launch */, u32 nvb,
+                                                  FuseState* fs, HistSync* hs /* zero at launch */, u32 nvb,
                                                   u32* errword /* page-locked host memory, or NULL */) {
   if (*hit) return;   // the speculative window already produced this step's median
   __shared__ u32 h[2 * STEIN_HIST_BINS];
-  __shared__ u32 s_v, s_last;
+  __shared__ u32 s_v, s_flag;
   const int first = *skip_l0 == 0u ? 0 : 1;   // level 0 may have been taken by the distance kernel (an earlier launch)
   ChainState cs = chain_resolve<false>(hist_all, first, st);
+  const HistSync::Line* myline = &hs->line[blockIdx.x % HS_CLASSES];
   for (int level = first; level < STEIN_HIST_LEVELS; ++level) {
-    for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
-    if (threadIdx.x == 0) s_v = __hip_atomic_fetch_add(&fs->draw[level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    u32 v = s_v, took = 0u;
-    while (v < nvb) {
-      __syncthreads();   // everybody has read s_v
-      // the next draw flies under this virtual workgroup's pass (with the whole grid resident it comes back >= nvb)
-      if (threadIdx.x == 0) s_v = __hip_atomic_fetch_add(&fs->draw[level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (level == 0) hist_pass_body<0, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
-      else if (level == 1) hist_pass_body<1, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
-      else hist_pass_body<2, true>(D, ldD, n, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
-      ++took;
-      __syncthreads();
-      v = s_v;
-    }
-    if (took) {
-      u64* hl = hist_all + (size_t)level * 2 * STEIN_HIST_BINS;
-      for (int b = threadIdx.x; b < (cs.two ? 2 : 1) * STEIN_HIST_BINS; b += 256)
-        if (h[b]) atomicAdd(&hl[b], (u64)h[b]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's histogram atomics have been acknowledged
-    __syncthreads();
+    const u32 want = (u32)(level - first + 1);
+    // this workgroup's own virtual workgroup, unless somebody has taken it over
     if (threadIdx.x == 0)
-      s_last = took && __hip_atomic_fetch_add(&fs->done[level], took, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + took == nvb ? 1u : 0u;
-    __syncthreads();
-    const bool last = s_last != 0u;
-    if (level + 1 == STEIN_HIST_LEVELS) {   // behind the last level: the resolver finishes the select, everybody else leaves
-      if (last) {
+      s_v = blockIdx.x < nvb && __hip_atomic_exchange(&hs->claim[level][blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u
+                ? blockIdx.x : nvb;
+    bool last = false, thief = false;
+    for (;;) {
+      for (int b = threadIdx.x; b < 2 * STEIN_HIST_BINS; b += 256) h[b] = 0u;
+      __syncthreads();
+      const u32 v = s_v;
+      if (v < nvb) {
+        if (level == 0) hist_pass_sym<0>(D, ldD, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
+        else if (level == 1) hist_pass_sym<1>(D, ldD, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
+        else hist_pass_sym<2>(D, ldD, n, h, cs.prefix[0], cs.prefix[1], cs.two, v, nvb);
+        __syncthreads();
+        u64* hl = hist_all + (size_t)level * 2 * STEIN_HIST_BINS;
+        for (int b = threadIdx.x; b < (cs.two ? 2 : 1) * STEIN_HIST_BINS; b += 256)
+          if (h[b]) atomicAdd(&hl[b], (u64)h[b]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's histogram atomics have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = hs_report_done(hs, level, v, nvb) ? 1u : 0u;
+        __syncthreads();
+        last = s_flag != 0u;
+        if (last) break;
+      }
+      if (!thief) {   // wait for the level to be published -- for a while
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = hs_wait(&myline->gen, want, HIST_PATIENCE) ? 1u : 0u;
+        __syncthreads();
+        if (s_flag) break;
+        thief = true;   // out of patience: somebody's virtual workgroup may have no owner
+      }
+      const u32 more = hs_steal(hs, level, nvb);
+      if (more < nvb) {   // an abandoned virtual workgroup, now ours
+        if (threadIdx.x == 0) s_v = more;
+        __syncthreads();
+        continue;
+      }
+      // nothing is abandoned (any more): whoever claimed the rest is running and will report it
+      if (threadIdx.x == 0) {
+        const bool ok = hs_wait(&myline->gen, want, HIST_SPIN_MAX);
+        if (!ok) __hip_atomic_store(&fs->gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      break;
+    }
+    const bool final_level = level + 1 == STEIN_HIST_LEVELS;
+    if (last) {   // the level's resolver
+      if (final_level) {
         resolve_all_body(hist_all, fin.st, fin.sp, fin.ln_n, fin.h2_out);
         if (threadIdx.x == 0 && load_fresh(&fs->gave_up)) {   // a wait ran out somewhere: no median, and loudly so
           fin.st->median = fin.st->h2 = __builtin_nanf("");
           if (fin.h2_out) *fin.h2_out = __builtin_nanf("");
           if (errword) __hip_atomic_store(errword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+      } else {
+        cs = chain_resolve<true>(hist_all, level + 1, st);
       }
-      return;
-    }
-    const u32 want = (u32)(level - first + 1);
-    if (last) {
-      cs = chain_resolve<true>(hist_all, level + 1, st);
-      if (threadIdx.x == 0) {
+      if (threadIdx.x < HS_CLASSES) {   // one thread per class line: the state first, then (acknowledged) the generation
+        HistSync::Line* ln = &hs->line[threadIdx.x];
         const u32 w[6] = {cs.prefix[0], cs.prefix[1], (u32)cs.rank[0], (u32)(cs.rank[0] >> 32), (u32)cs.rank[1], (u32)(cs.rank[1] >> 32)};
 #pragma unroll
-        for (int k = 0; k < 6; ++k) __hip_atomic_store(&fs->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(&ln->pub[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&fs->gen, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ln->gen, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      continue;
+      continue;   // (behind the final level the loop ends)
     }
-    if (threadIdx.x == 0) {
-      int spin = 0;
-      for (; spin < HIST_SPIN_MAX && load_fresh(&fs->gen) < want; ++spin) __builtin_amdgcn_s_sleep(8);
-      if (spin == HIST_SPIN_MAX) __hip_atomic_store(&fs->gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
+    if (final_level) return;   // the select is complete (or, gave_up, declared failed); nobody needs the state any more
     // (a workgroup that started late may read the state of a LATER level here, or a mix of two: then that later level was
-    // complete before the read, its draw counter is exhausted, and the state is never used)
+    // complete before the read, all of its virtual workgroups are claimed, and the state is never used)
     u32 w[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = load_fresh(&fs->pub[k]);
+    for (int k = 0; k < 6; ++k) w[k] = load_fresh(&myline->pub[k]);
     cs.prefix[0] = w[0]; cs.prefix[1] = w[1];
     cs.rank[0] = (u64)w[2] | ((u64)w[3] << 32); cs.rank[1] = (u64)w[4] | ((u64)w[5] << 32);
     cs.two = w[0] != w[1];
@@ -530,7 +609,7 @@ __global__ __launch_bounds__(256) void k_prologue(const TIN* __restrict__ T, Pro
   prologue_body<TIN>(T, a, (int)blockIdx.x, (int)gridDim.x);
 }
 
-__device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* sp);   // below
+__device__ __attribute__((noinline)) void spec_update_dev(const SelState* st, SpecState* sp);   // below
 
 // All 256 bins of an LDS histogram -> the bin holding 0-based rank `rank` and the rank inside it; *bin = 256 when the
 // rank lies past the last bin.  Called by the whole workgroup (>= 256 threads); `scan` is 256 words of LDS scratch.
@@ -795,7 +874,7 @@ __global__ __launch_bounds__(1024) void k_spec_pick(SelState* st, SpecState* sp,
 }
 
 // after the median is final (window or radix passes): predict the next one and size its window (one thread)
-__device__ __forceinline__ void spec_update_dev(const SelState* st, SpecState* sp) {
+__device__ __attribute__((noinline)) void spec_update_dev(const SelState* st, SpecState* sp) {
   const u32 key = f32_key(st->lo);
   const bool had_window = sp->width != 0u;
   u32 hw = 4096u, next = key;
@@ -829,7 +908,9 @@ __global__ void k_spec_update(const SelState* st, SpecState* sp) {
 
 // end of the chained radix select (fused call): all three resolves, the median / bandwidth, the predictor update;
 // one workgroup of 256 threads
-__device__ __forceinline__ void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out) {
+// (not inlined, like chain_resolve and hs_steal: inlined into k_hist_all their constants and addresses were hoisted in front
+// of the level loop -- 114 registers, four workgroups per CU instead of eight, for code that one workgroup runs once)
+__device__ __attribute__((noinline)) void resolve_all_body(u64* hist_all, SelState* st, SpecState* sp, float ln_n, float* h2_out) {
   const ChainState cs = chain_resolve<true>(hist_all, STEIN_HIST_LEVELS, st);
   if (threadIdx.x == 0) {
     st->prefix[0] = cs.prefix[0]; st->prefix[1] = cs.prefix[1];
@@ -990,6 +1071,12 @@ __global__ __launch_bounds__(NTHREADS) void k_phi_partial(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // k_phi_finish: sum the split partials, form phi, per-block partial |phi|^2 in fp64
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 theta4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 theta4(const unsigned short* p) {   // four bf16 values (8-byte aligned)
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                     __uint_as_float(w.y & 0xffff0000u));
+}
 template <typename TIN>
 __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG, const float* __restrict__ OT,
                                                     const float* __restrict__ RS, const TIN* __restrict__ T,
@@ -1005,9 +1092,9 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
   const long total = (long)n_local * d;
   const size_t zs = (size_t)n_local * d;
   double sq = 0.0;
-  if (sizeof(TIN) == 4 && vec) {   // host: d % 4 == 0 and every pointer 16-byte aligned
+  if (vec) {   // host: d % 4 == 0 and every pointer aligned for four columns at a time
     // four consecutive columns of one row per step, 16-byte loads and stores (one entry at a time with an integer
-    // division each, the kernel moved its 68 MB at 2.8 TB/s)
+    // division each, the kernel moved its 68 MB at 2.8 TB/s; bf16 inputs took that path until round 4: 19 us at C2)
     const long total4 = total >> 2;
     const int d4 = d >> 2;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += (long)gridDim.x * 256) {
@@ -1022,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
         ot.x += b.x; ot.y += b.y; ot.z += b.z; ot.w += b.w;
         rs += RS[(size_t)z * n_local + i];
       }
-      const float4 th = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(T) + (size_t)row0 * d + e);
+      const float4 th = theta4(T + (size_t)row0 * d + e);
       float4 dk, ph;
       dk.x = (rs * th.x - ot.x) / h2; dk.y = (rs * th.y - ot.y) / h2; dk.z = (rs * th.z - ot.z) / h2; dk.w = (rs * th.w - ot.w) / h2;
       ph.x = (og.x + dk.x) / fn; ph.y = (og.y + dk.y) / fn; ph.z = (og.z + dk.z) / fn; ph.w = (og.w + dk.w) / fn;
@@ -1544,13 +1631,14 @@ static int contract_finish_impl(const void* theta_all, int64_t n, int64_t d, int
   double* SQ = (double*)(ws + L.off[STEIN_WS_SQPART]);
   hipStream_t s = (hipStream_t)stream;
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+  const size_t tsz = dtype == STEIN_BF16 ? 2 : 4;
   const int vec = (d % 4 == 0) && al16(OG) && al16(OT) && al16(phi_local) && al16(dK_out) &&
-                  al16((const float*)theta_all + (size_t)row0 * d);
+                  (((uintptr_t)theta_all + (size_t)row0 * d * tsz) & (4 * tsz - 1)) == 0;
   if (L.sq_blocks > 512) fuse_done = nullptr;   // a ticket per workgroup: beyond a few hundred the separate launch is cheaper
   if (dtype == STEIN_BF16)
     hipLaunchKernelGGL(k_phi_finish<unsigned short>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
                        (const unsigned short*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0,
-                       (int)n_local, (int)L.split, 0, fuse_done, sqnorm_out);
+                       (int)n_local, (int)L.split, vec, fuse_done, sqnorm_out);
   else
     hipLaunchKernelGGL(k_phi_finish<float>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
                        (const float*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0, (int)n_local,
@@ -1727,10 +1815,15 @@ int stein_take_device_error(void) {
 }
 // test hooks (per calling thread; tests/test_gpu_spec.py): launch k_hist_all with this many workgroups instead of one per
 // virtual workgroup (0 = default); raise the current device's error word as a kernel would
-static thread_local int g_hist_all_grid = 0;
+static thread_local int g_hist_all_grid = 0, g_hist_all_nvb = 0;
 extern "C" int stein_debug_hist_all_grid(int blocks) {
   if (blocks < 0 || blocks > 65535) return fail(STEIN_E_BADARG, "blocks %d", blocks);
   g_hist_all_grid = blocks;
+  return STEIN_OK;
+}
+extern "C" int stein_debug_hist_all_vblocks(int nvb) {   // (tuning aid: virtual workgroups per level, 0 = default)
+  if (nvb < 0 || nvb > 65535) return fail(STEIN_E_BADARG, "nvb %d", nvb);
+  g_hist_all_nvb = nvb;
   return STEIN_OK;
 }
 extern "C" int stein_debug_raise_device_error(void) {
@@ -1835,6 +1928,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     pa.n = (int)n; pa.d = (int)d; pa.r = r; pa.st = (SelState*)sel; pa.sp = spec; pa.fs = fuse; pa.total = (u64)(n * n);
     pa.hist = (u64*)hist; pa.slots = spec_buf; pa.cmax = cmax; pa.ncmax = ncmax;
     pa.allow_window = (flags & STEIN_FLAG_NO_WINDOW) ? 0 : 1;
+    pa.hsync = (u32*)spec_table_of(spec_buf); pa.hsync_words = (int)(sizeof(HistSync) / 4);
     pa.neutral_sc = (dtype == STEIN_BF16 && planes) ? (float*)((char*)planes + L.x3_sc) : (float*)nullptr;
     pa.dc = (int)L.x3_dc;
     if (dtype == STEIN_BF16 && planes) {
@@ -1871,14 +1965,29 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   if (!solo) {
     const HistFinal fin{(SelState*)sel, spec, h2_out, (float)log((double)n)};
     const long units = ((n + DT_ROWS - 1) / DT_ROWS) * ((n + DT_COLS - 1) / DT_COLS);
-    const long want = n <= HIST_ALL_SMALL_N ? HIST_ALL_VBLOCKS : HIST_BLOCKS;
+    // large blocks: as many virtual workgroups as the chip holds at once (the passes like many loads in flight, and a grid
+    // beyond residency would leave the surplus to the thieves); small ones: 512 (measured at C2)
+    long want = HIST_ALL_VBLOCKS;
+    if (n > HIST_ALL_SMALL_N) {
+      static int resident = 0;   // (a benign race: every thread computes the same value)
+      if (!resident) {
+        int per_cu = 0, dev = 0, ncu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hist_all, 256, 0));
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const long r = (long)(per_cu > 0 ? per_cu : 4) * (ncu > 0 ? ncu : 256);
+        resident = (int)(r > HIST_BLOCKS ? HIST_BLOCKS : r);
+      }
+      want = resident;
+    }
+    if (g_hist_all_nvb > 0) want = g_hist_all_nvb;
     const int nvb = (int)(units < want ? units : want);
     const int blocks = g_hist_all_grid > 0 ? g_hist_all_grid : nvb;   // (test hook: any grid >= 1 must give the same median)
     u32* errword = nullptr;
     if ((rc = device_error_word(&errword))) return rc;
     hipLaunchKernelGGL(k_hist_all, dim3(blocks), dim3(256), 0, s, (const float*)D, (long)L.ld_dist, (int)n,
                        (const SelState*)sel, (u64*)hist, (const u32*)&spec->hit, (const u32*)&spec->skip_l0, fin, fuse,
-                       (u32)nvb, errword);
+                       (HistSync*)spec_table_of(spec_buf), (u32)nvb, errword);
     LAUNCH_CHECK("k_hist_all");
   }
   // the split path's symmetric distance pass stores only the tiles on and above the diagonal
