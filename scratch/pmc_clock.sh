@@ -11,7 +11,7 @@ rocprofv3 --list-avail > $OUT/avail.txt 2>&1
 grep -o "GRBM_[A-Z_]*" $OUT/avail.txt | sort -u | tr '\n' ' ' > $OUT/grbm_counters.txt
 for C in "GRBM_COUNT GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   N=$(echo $C | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$N -o x -- python3 $GRAFT_REPO_ROOT/scratch/fused_loop.py ${LIB:-shipped} 16384 256 12 > $OUT/$N.log 2>&1 || echo "counter set $N refused" >&2
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$N -o x -- python3 $GRAFT_REPO_ROOT/scratch/${SCRIPT:-fused_loop.py} ${LIB:-shipped} ${ARGS:-16384 256 12} > $OUT/$N.log 2>&1 || echo "counter set $N refused" >&2
 done
 python3 - <<PY
 import csv, glob, os, collections, json
