@@ -26,7 +26,7 @@ on), `frac` = achieved / peak (= `frac_algorithmic`).  The split path executes 3
 reach at most); the strict fp32-input MFMA kernels are timed under `fp32_path`.
 
 wall_minus_events_ms (every timed entry): wall time per step minus the GPU time the HIP events of the same steps bracket;
-`host_stall_suspected` when the gap exceeds max(0.05 ms, 25 %).  A stalled headline loop is timed once more (`retimed`).
+`host_stall_suspected` when the gap exceeds max(0.05 ms, 25 %).  A stalled timed loop (headline or variant) is timed once more (`retimed` keeps the first run).
 
 window: the headline step uses the speculative median window (exact, stein_common.h); `window` reports how many of the
 timed steps it delivered the median, and `miss_path` times the same steps with the window disabled (every step pays the
@@ -231,6 +231,19 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     return dict(comm=eng.comm, comm_note=comm_note, comm_crosscheck=crosscheck, n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, events_ms=events_ms, finite=finite, split=eng.split,
                 ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3, parity_relerr=relerr, parity_rows=nrows,
                 window=dict(timed_steps=stats1[0] - stats0[0], hits=stats1[1] - stats0[1]) if has_window else None)
+
+
+def run_stable(torch, dist, wl, device, rank, world, group, steps, warmup, **kw):
+    """run_workload, timed once more when the host, not the GPU, set the pace of the timed loop (one rank: wall time per step
+    beyond the event-bracketed GPU time by more than max(0.05 ms, 25 %)).  -> (result, None | what the first run measured)"""
+    res = run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, **kw)
+    if world != 1 or not gap_fields(res["elapsed"] / steps * 1e3, res["events_ms"])["host_stall_suspected"]:
+        return res, None
+    first = {"why": "wall time per step exceeded the event-bracketed GPU time by more than max(0.05 ms, 25 %): host stall; timed once more",
+             "first_run_ms_per_step": res["elapsed"] / steps * 1e3, "first_run_events_ms": res["events_ms"]}
+    del res
+    torch.cuda.empty_cache()
+    return run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, **kw), first
 
 
 def crosscheck_comms(torch, dist, wl, device, rank, world, group, steps=4):
@@ -467,16 +480,9 @@ def main():
         wl["name"] = "custom n=%d d=%d fp32" % (wl["n"], wl["d"])
     env_x3 = not args.fp32_mfma
     hx3 = False if args.fp32_mfma else None
-    res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3)
-    retimed = None
-    if world == 1 and gap_fields(res["elapsed"] / args.steps * 1e3, res["events_ms"])["host_stall_suspected"]:
-        # the host, not the GPU, set the pace of the timed loop (a stalled launch thread on a shared box): say so and time
-        # the same K steps once more; the line reports the second run and keeps the first one's numbers beside it
-        retimed = {"why": "wall time per step exceeded the event-bracketed GPU time by more than max(0.05 ms, 25 %): host stall",
-                   "first_run_ms_per_step": res["elapsed"] / args.steps * 1e3, "first_run_events_ms": res["events_ms"]}
-        del res
-        torch.cuda.empty_cache()
-        res = run_workload(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3)
+    # (a stalled timed loop -- a launch thread that lost its core on a shared box -- is timed once more; `retimed` keeps the
+    # first run's numbers)
+    res, retimed = run_stable(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3)
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
     value = n * args.steps / res["elapsed"]
@@ -588,8 +594,8 @@ def main():
     # one GPU: what the headline does not show -- a step whose window misses, and the strict fp32-input MFMA kernels
     if world == 1 and not args.no_variants and not wl.get("bf16") and env_x3:
         torch.cuda.empty_cache()
-        rm = run_workload(torch, dist, wl, device, rank, world, group, 10, 3, window=False)
-        out["miss_path"] = {"what": "the same step with the speculative median window disabled: every step runs the "
+        rm, rt_m = run_stable(torch, dist, wl, device, rank, world, group, 10, 3, window=False)
+        out["miss_path"] = {"retimed": rt_m, "what": "the same step with the speculative median window disabled: every step runs the "
                                     "radix-select passes over D (what a window miss costs)",
                             "steps": 10, "ms_per_step": rm["elapsed"] / 10 * 1e3,
                             "stage_ms": {k: round(v, 4) for k, v in rm["stages"].items()},
@@ -597,9 +603,9 @@ def main():
                             "parity_sample_relerr": rm["parity_relerr"]}
         del rm
         torch.cuda.empty_cache()
-        rf = run_workload(torch, dist, wl, device, rank, world, group, 5, 2, x3=False)
+        rf, rt_f = run_stable(torch, dist, wl, device, rank, world, group, 5, 2, x3=False)
         kf = rf["stages"].get("contract")
-        out["fp32_path"] = {"what": "the same step on the fp32-input MFMA kernels (x3=False): exact k-ordered fmaf chains",
+        out["fp32_path"] = {"retimed": rt_f, "what": "the same step on the fp32-input MFMA kernels (x3=False): exact k-ordered fmaf chains",
                             "steps": 5, "ms_per_step": rf["elapsed"] / 5 * 1e3,
                             "stage_ms": {k: round(v, 4) for k, v in rf["stages"].items()},
                             **gap_fields(rf["elapsed"] / 5 * 1e3, rf["events_ms"]),
@@ -610,8 +616,8 @@ def main():
 
     if world == 1 and not args.no_variants and not wl.get("bf16") and env_x3:
         torch.cuda.empty_cache()
-        rt = run_workload(torch, dist, wl, device, rank, world, group, 10, 3, tile_distance=True)
-        out["tile_distance_path"] = {"what": "the same step with the distance pass on the per-tile kernel (k_distance_x3, round 2's) "
+        rt, rt_t = run_stable(torch, dist, wl, device, rank, world, group, 10, 3, tile_distance=True)
+        out["tile_distance_path"] = {"retimed": rt_t, "what": "the same step with the distance pass on the per-tile kernel (k_distance_x3, round 2's) "
                                              "instead of the panel-resident one: same-box A/B",
                                      "steps": 10, "ms_per_step": rt["elapsed"] / 10 * 1e3,
                                      "stage_ms": {k: round(v, 4) for k, v in rt["stages"].items()},
@@ -627,7 +633,7 @@ def main():
         free = torch.cuda.mem_get_info(device)[0]
         if need < free * 0.9:
             torch.cuda.empty_cache()
-            r2 = run_workload(torch, dist, wl2, device, rank, world, group, args.secondary_steps, 3, comm=args.comm)   # 3 warm-up steps: the median predictor needs two medians of history
+            r2, rt_2 = run_stable(torch, dist, wl2, device, rank, world, group, args.secondary_steps, 3, comm=args.comm)   # 3 warm-up steps: the median predictor needs two medians of history
             k2 = r2["stages"].get("contract")
             f2 = 4.0 * r2["n_local"] * r2["n"] * r2["d"]
             np2 = (1 if wl2.get("bf16") else 3) if r2["x3"] else 1     # 16-bit products per operand pair (1: the fp32-input MFMA kernel)
@@ -635,7 +641,7 @@ def main():
             out["secondary_value"] = r2["n"] * args.secondary_steps / r2["elapsed"]
             out["secondary_config"] = "%s: n=%d d=%d, %d ranks, %d timed steps" % (args.secondary, r2["n"], r2["d"], world, args.secondary_steps)
             out["secondary"] = {
-                "workload": wl2["name"], "n": r2["n"], "d": r2["d"], "steps": args.secondary_steps,
+                "retimed": rt_2, "workload": wl2["name"], "n": r2["n"], "d": r2["d"], "steps": args.secondary_steps,
                 "ms_per_step": r2["elapsed"] / args.secondary_steps * 1e3,
                 "value": r2["n"] * args.secondary_steps / r2["elapsed"], "unit": "particle-updates/s",
                 "scaling": "strong (fixed n=%d)" % r2["n"],
