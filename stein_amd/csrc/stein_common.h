@@ -154,7 +154,23 @@ struct HistSync {
   struct Top { u32 classes; u32 pad[15]; } top[STEIN_HIST_LEVELS];               // classes that are complete
   struct Line { u32 gen; u32 pub[6]; u32 pad[9]; } line[HS_CLASSES];   // per class: levels published so far + the select
                                                                        // state the resolver published (prefix[2], rank[2] as halves)
+  // k_phi_finish (fused call): the same two-level completion count lets its last workgroup sum the |phi|^2 partials
+  // whatever the grid (round 3's single ticket was only worth it up to 512 workgroups)
+  Leaf fin_leaf[HS_CLASSES];
+  Top fin_top;
+  // k_colmax (fused call, fp32 inputs): its last workgroup turns the column maxima into the scales
+  Leaf cm_leaf[HS_CLASSES];
+  Top cm_top;
 };
+// thread 0 of a workgroup whose results have been acknowledged: is this the last of `nblocks` workgroups to report?  A
+// two-level tree (64 leaves, one top): no counter sees more than nblocks / 64 returning atomics.  Counters zero at launch.
+__device__ __forceinline__ bool tree_report_done(HistSync::Leaf* leaf, HistSync::Top* top, u32 id, u32 nblocks) {
+  const u32 c = id % HS_CLASSES;
+  const u32 quota = (nblocks - c + HS_CLASSES - 1) / HS_CLASSES;
+  if (__hip_atomic_fetch_add(&leaf[c].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != quota) return false;
+  const u32 nclasses = nblocks < (u32)HS_CLASSES ? nblocks : (u32)HS_CLASSES;
+  return __hip_atomic_fetch_add(&top->classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nclasses;
+}
 static_assert(sizeof(HistSync) % 8 == 0, "HistSync is carved out of a u64 table");
 constexpr u32 SPEC_MAGIC1 = 0x5EED0001u, SPEC_MAGIC2 = 0x5EED0002u;
 constexpr u32 SPEC_QCAP = 1016;          // per-workgroup LDS queue (entries of 8 bytes; shares its LDS with the histogram)

@@ -5,7 +5,7 @@
 // dtype = STEIN_F32: fp32 inputs, two fp16 planes, three products; STEIN_BF16: bf16 inputs, one plane, one product
 int stein_x3_kind(int dtype);   // 1 or 2
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d, const SteinLayout& L,
-                   char* planes, hipStream_t stream, u32* fuse_done = nullptr, bool scales_written = false,
+                   char* planes, hipStream_t stream, HistSync* fuse_done = nullptr, bool scales_written = false,
                    const PrologueArgs* prologue = nullptr /* fused call, bf16: the launch also does the prologue's work */);
 int stein_x3_distance(const char* planes, const SteinLayout& L, int dtype, const float* r_all, float* dist_out,
                       int64_t n, int64_t d, int64_t row0, int64_t n_local, int64_t ld_dist, u64* hist0, bool symmetric,

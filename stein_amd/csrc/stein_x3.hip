@@ -152,12 +152,12 @@ __device__ __forceinline__ void make_scales_body(const u32* cmax, int dc, float*
 
 // column maxima of |X| [n][d] as bit patterns (non-negative floats order like unsigned integers)
 // blockIdx.z = 0: X0 -> cmax[0, dc), 1: X1 -> cmax[dc, 2 dc)
-// done != NULL (fused call: both matrices given, counter zeroed beforehand): the last workgroup to finish also turns
-// the maxima into the scales, which saves the k_make_scales launch.
+// done != NULL (fused call: both matrices given, completion counters zeroed by the prologue): the last workgroup to finish
+// also turns the maxima into the scales, which saves the k_make_scales launch (round 4: a two-level count, so whatever the grid).
 template <typename TIN>
 __global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
                                                 u32* __restrict__ cmax0, int dc, int zbase, float* __restrict__ sc,
-                                                int pexp, u32* done) {
+                                                int pexp, HistSync* done) {
   const int z = blockIdx.z + zbase;
   const TIN* __restrict__ X = z ? X1 : X0;
   u32* __restrict__ cmax = cmax0 + (z ? dc : 0);
@@ -181,8 +181,17 @@ __global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, cons
   red[ry][cx] = m;
   __syncthreads();
   if (ry == 0 && col < d) atomicMax(&cmax[col], max(max(red[0][cx], red[1][cx]), max(red[2][cx], red[3][cx])));
-  if (done && last_workgroup_out(done, gridDim.x * gridDim.y * gridDim.z))
-    make_scales_body(cmax0, dc, sc, pexp, 1, &red[0][0]);
+  if (done) {
+    __shared__ u32 s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's maxima have been acknowledged
+    __syncthreads();
+    if (t == 0) {
+      const u32 id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      s_last = tree_report_done(done->cm_leaf, &done->cm_top, id, gridDim.x * gridDim.y * gridDim.z) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) make_scales_body(cmax0, dc, sc, pexp, 1, &red[0][0]);
+  }
 }
 
 // one workgroup: maxima -> the scales area
@@ -895,7 +904,7 @@ static void launch_split(hipStream_t stream, const TIN* theta, const TIN* score,
 // fuse_done != NULL (fused call): the caller has zeroed the column maxima and the ticket, both matrices are given, and
 // the column-maxima kernel's last workgroup writes the scales itself
 int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int64_t n, int64_t d,
-                   const SteinLayout& L, char* planes, hipStream_t stream, u32* fuse_done, bool scales_written,
+                   const SteinLayout& L, char* planes, hipStream_t stream, HistSync* fuse_done, bool scales_written,
                    const PrologueArgs* prologue) {
   u16* T3 = reinterpret_cast<u16*>(planes + L.x3_t3);
   u16* Tt3 = reinterpret_cast<u16*>(planes + L.x3_tt3);
@@ -912,9 +921,6 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
     int gy = (int)((n + 63) / 64);
     if (gy > 256) gy = 256;
     const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, nz);
-    // a ticket per workgroup is one more same-address atomic each: beyond a few hundred workgroups the separate
-    // k_make_scales launch is the cheaper way
-    if ((long)grid.x * grid.y * grid.z > 512) fuse_done = nullptr;
     hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (const float*)theta_all,
                        (int)n, (int)d, cmax, dc, zbase, sc, PEXP_H2, fuse_done);
     LAUNCH_CHECK("k_colmax");

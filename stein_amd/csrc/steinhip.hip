@@ -399,11 +399,7 @@ static_assert(HIST_BLOCKS <= HS_NV, "HistSync::claim holds one flag per virtual 
 
 // thread 0: virtual workgroup v of `level` is done (its counts have reached the global histogram) -> is this the last one?
 __device__ __forceinline__ bool hs_report_done(HistSync* hs, int level, u32 v, u32 nvb) {
-  const u32 c = v % HS_CLASSES;
-  const u32 quota = (nvb - c + HS_CLASSES - 1) / HS_CLASSES;          // virtual workgroups of class c
-  if (__hip_atomic_fetch_add(&hs->leaf[level][c].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != quota) return false;
-  const u32 nclasses = nvb < (u32)HS_CLASSES ? nvb : (u32)HS_CLASSES;
-  return __hip_atomic_fetch_add(&hs->top[level].classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nclasses;
+  return tree_report_done(hs->leaf[level], &hs->top[level], v, nvb);
 }
 // whole workgroup: an unclaimed virtual workgroup of `level`, claimed for the caller; nvb if there is none.  Every thief
 // scans from a start of its own (workgroup id x a stride coprime to any nvb <= 2048, + the number of its attempt): a
@@ -1082,10 +1078,10 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
                                                     const float* __restrict__ RS, const TIN* __restrict__ T,
                                                     const float* __restrict__ h2p, float* __restrict__ phi,
                                                     float* __restrict__ dK, double* __restrict__ sqpart, int n, int d,
-                                                    int row0, int n_local, int split, int vec, u32* done,
+                                                    int row0, int n_local, int split, int vec, HistSync* done,
                                                     double* __restrict__ sq_out) {
-  // done != NULL (fused call, small grids): the last workgroup out also sums the partials -- in the order k_sum_partials
-  // uses, so the result is the same to the last bit -- which saves that launch
+  // done != NULL (fused call; its completion counters are zero at launch): the last workgroup out also sums the partials --
+  // in the order k_sum_partials uses, so the result is the same to the last bit -- which saves that launch
   __shared__ double red[4];
   const float h2 = *h2p;
   const float fn = (float)n;
@@ -1146,7 +1142,14 @@ __global__ __launch_bounds__(256) void k_phi_finish(const float* __restrict__ OG
   // the partials cross workgroups: written with device-scope atomics, read with load_fresh (last_workgroup_out)
   if (threadIdx.x == 0)
     __hip_atomic_store(reinterpret_cast<u64*>(sqpart) + blockIdx.x, (u64)__double_as_longlong(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!last_workgroup_out(done, gridDim.x)) return;
+  {
+    __shared__ u32 s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial has been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = tree_report_done(done->fin_leaf, &done->fin_top, blockIdx.x, gridDim.x) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+  }
   double s2 = 0.0;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) s2 += __longlong_as_double((long long)load_fresh(reinterpret_cast<const u64*>(sqpart) + i));
 #pragma unroll
@@ -1616,7 +1619,7 @@ extern "C" int stein_contract_partial(const float* dist, int64_t ld_dist, const 
 
 static int contract_finish_impl(const void* theta_all, int64_t n, int64_t d, int64_t row0, int64_t n_local,
                                 int dtype, const float* h2_dev, float* phi_local, double* sqnorm_out,
-                                float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream, u32* fuse_done) {
+                                float* dK_out, void* workspace, size_t ws_bytes, int flags, void* stream, HistSync* fuse_done) {
   if (!theta_all || !h2_dev || !phi_local || !sqnorm_out || !workspace) return fail(STEIN_E_BADARG, "NULL pointer");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "contract: dtype %d", dtype);
   if (row0 < 0 || row0 + n_local > n) return fail(STEIN_E_SHAPE, "bad row block");
@@ -1634,7 +1637,6 @@ static int contract_finish_impl(const void* theta_all, int64_t n, int64_t d, int
   const size_t tsz = dtype == STEIN_BF16 ? 2 : 4;
   const int vec = (d % 4 == 0) && al16(OG) && al16(OT) && al16(phi_local) && al16(dK_out) &&
                   (((uintptr_t)theta_all + (size_t)row0 * d * tsz) & (4 * tsz - 1)) == 0;
-  if (L.sq_blocks > 512) fuse_done = nullptr;   // a ticket per workgroup: beyond a few hundred the separate launch is cheaper
   if (dtype == STEIN_BF16)
     hipLaunchKernelGGL(k_phi_finish<unsigned short>, dim3((unsigned)L.sq_blocks), dim3(256), 0, s, OG, OT, RS,
                        (const unsigned short*)theta_all, h2_dev, phi_local, dK_out, SQ, (int)n, (int)d, (int)row0,
@@ -1914,8 +1916,9 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   // The prologue carries the row norms and all set-up; kernels let their last workgroup do what a one-workgroup follow-up
   // launch would (FuseState tickets: scales, |phi|^2 sum); the chained radix select is ONE launch (k_hist_all) and none
   // for n <= SOLO_MAX_N (k_spec_select covers it); bf16 inputs need no scales, so their prologue rides in the split's
-  // launch.  fp32 inputs: k_prologue, k_colmax, k_split, distance, k_spec_select, k_hist_all, contraction, k_phi_finish
-  // (+ k_sum_partials beyond 512 workgroups): eight or nine launches whatever n; bf16 at C2's size: six.
+  // launch.  fp32 inputs: k_prologue, k_colmax, k_split, distance, k_spec_select, k_hist_all, contraction, k_phi_finish:
+  // eight launches whatever n (the last workgroups of k_colmax and k_phi_finish are found with two-level completion counts,
+  // HistSync, so no grid is too large for them); bf16 inputs: six.
   FuseState* fuse = (FuseState*)((char*)sel + sizeof(SelState) + sizeof(SpecState));
   {
     u32* cmax = nullptr;
@@ -1934,7 +1937,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     if (dtype == STEIN_BF16 && planes) {
       // bf16 inputs need no scales, so the split does not depend on the prologue: both ride in ONE launch (k_split's grid
       // gets a third slice that does the prologue's work) -- one launch less on the latency-bound sizes this dtype is for
-      if ((rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax, true, &pa))) return rc;
+      if ((rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, (HistSync*)spec_table_of(spec_buf), true, &pa))) return rc;
     } else {
       const int row_blocks = (int)((n + 3) / 4);
       const dim3 grid((unsigned)(row_blocks + PRO_INIT_BLOCKS));
@@ -1943,7 +1946,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
       else
         hipLaunchKernelGGL(k_prologue<float>, grid, dim3(256), 0, s, (const float*)theta_all, pa);
       LAUNCH_CHECK("k_prologue");
-      if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, &fuse->done_colmax, false, nullptr)))
+      if (planes && (rc = stein_x3_split(theta_all, score_all, dtype, n, d, L, (char*)planes, s, (HistSync*)spec_table_of(spec_buf), false, nullptr)))
         return rc;
     }
   }
@@ -1999,7 +2002,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
     return rc;
   STEIN_TSTAMP(STEIN_T_FINISH);
   if ((rc = contract_finish_impl(theta_all, n, d, row0, n_local, dtype, h2_out, phi_local, sqnorm_out, dK_out, workspace,
-                                ws_bytes, planes ? STEIN_FLAG_X3 : 0, stream, &fuse->done_finish)))
+                                ws_bytes, planes ? STEIN_FLAG_X3 : 0, stream, (HistSync*)spec_table_of(spec_buf))))
     return rc;
   STEIN_TSTAMP(STEIN_T_NSTAGES);
 #undef STEIN_TSTAMP
