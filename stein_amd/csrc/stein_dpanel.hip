@@ -25,6 +25,7 @@
 // SYM (single rank): only strips on and above the diagonal exist; off-diagonal tiles count twice (weight 2) and are
 // stored once (the contraction reads the others transposed).  The four strips of a diagonal tile store entry by entry:
 // (i, j) for i <= j and, for i < j, the same VALUE at (j, i) -- D is exactly symmetric whatever the product order was.
+#include <type_traits>
 #include "stein_x3.h"
 #include "stein_x3_dev.h"
 #define STEIN_ABLATE_DPANEL
@@ -131,6 +132,33 @@ __device__ __forceinline__ void dp_count4(DpWin& sx, const float (&v)[4], const 
         if (in) {
           if (idx < (u32)DP_QCAP) sx.q[idx] = ((u64)(__float_as_uint(v[e]) | 0x80000000u) << 2) | (UNIT ? wt : w[e]);
         }
+        sx.qn += (u32)__popcll(m);
+      }
+    }
+    if (sx.qn > (u32)DP_QCAP) { sx.over = 1u; sx.qn = DP_QCAP; }
+  }
+}
+
+// the eight values a lane holds of one 16-row block (two column blocks x four columns), every weight `wt`: the same
+// counting, one min-tree and one branch for all eight
+__device__ __forceinline__ void dp_count8(DpWin& sx, const float (&v)[2][4], u32 wt, int lane) {
+  u32 mn = 0xffffffffu, cnt = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u32 raw = __float_as_uint(v[k >> 2][k & 3]);
+    cnt += (u32)__popcll(__ballot((int)raw < (int)sx.lo));   // signed compare of the raw bits: negative values are below too
+    mn = min(mn, raw - sx.lo);
+  }
+  sx.below += cnt * wt;
+  if (__builtin_expect(__ballot(mn <= sx.width) != 0ull, 0)) {   // rare: a fraction of a percent of the blocks
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // (the offsets are formed again here: eight registers less across the hot path)
+      const u32 raw = __float_as_uint(v[k >> 2][k & 3]);
+      const bool in = raw - sx.lo <= sx.width;
+      const u64 m = __ballot(in);
+      if (m) {
+        const u32 idx = sx.qn + (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+        if (in && idx < (u32)DP_QCAP) sx.q[idx] = ((u64)(raw | 0x80000000u) << 2) | wt;
         sx.qn += (u32)__popcll(m);
       }
     }
@@ -380,7 +408,9 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
 #define DP_RI(ib) ri[ib]
+#define DP_EPI_FAST
 #include "stein_dpanel_epilogue.inc"
+#undef DP_EPI_FAST
 #undef DP_RI
         regular = !diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
