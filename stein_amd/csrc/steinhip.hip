@@ -1984,6 +1984,7 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
       want = resident;
     }
     if (g_hist_all_nvb > 0) want = g_hist_all_nvb;
+    if (want > HS_NV) want = HS_NV;   // (HistSync::claim holds one flag per virtual workgroup)
     const int nvb = (int)(units < want ? units : want);
     const int blocks = g_hist_all_grid > 0 ? g_hist_all_grid : nvb;   // (test hook: any grid >= 1 must give the same median)
     u32* errword = nullptr;
