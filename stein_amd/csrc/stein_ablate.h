@@ -6,7 +6,7 @@
 // timing-only ablations of k_distance_panel (wrong results; -DSTEIN_DP_ABL_NOSTORE: the regular strips keep their values alive
 // but store nothing)
 #ifdef STEIN_DP_ABL_NOSTORE
-#define DP_STORE16(ptr, val) asm volatile("" :: "v"((val).x), "v"((val).y), "v"((val).z), "v"((val).w), "v"(ptr))
+#define DP_STORE16(ptr, val) asm volatile("" :: "v"((val).x), "v"((val).y), "v"((val).z), "v"((val).w))   /* (the address is not kept alive: inside the epilogue's lambda an asm operand does not capture it) */
 #elif defined(STEIN_DP_SC1_STORE)   // (experiment: write-through stores for D)
 typedef float dp_f4w __attribute__((ext_vector_type(4)));
 #define DP_STORE16(ptr, val) do { const dp_f4w v_ = {(val).x, (val).y, (val).z, (val).w}; float* p_ = (ptr); asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p_), "v"(v_) : "memory"); } while (0)

@@ -85,10 +85,14 @@ __device__ __forceinline__ void dp_step(const unsigned char* pk /* panel k tile 
   for (int s = 0; s < NP; ++s) b[0][s] = *reinterpret_cast<const u32x4*>(pk + s * XPLANE);
 #pragma unroll
   for (int ib = 0; ib < 8; ++ib) {
+#ifdef STEIN_DP_ABL_NOPANEL   // (timing-only ablation: one LDS fragment read per k tile instead of eight)
+    b[(ib + 1) & 1][0] = b[ib & 1][0]; b[(ib + 1) & 1][1] = b[ib & 1][1];
+#else
     if (ib + 1 < 8) {
 #pragma unroll
       for (int s = 0; s < NP; ++s) b[(ib + 1) & 1][s] = *reinterpret_cast<const u32x4*>(pk + s * XPLANE + (ib + 1) * 1024);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = x3_products16<NP>(a[jb], b[ib & 1], acc[ib][jb]);
@@ -352,6 +356,10 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
       // a diagnostic build with more SGPR pressure sent its atomics to address 0).
       auto request = [&](const u16* sbase, int kt, u32x4 (&slot)[2][3]) {
         const u16* src = sbase + (size_t)(kt < ntk ? kt : ntk - 1) * 3 * XTILE_E;   // past the end: a harmless re-read keeps the counts
+#ifdef STEIN_DP_ABL_NOSTREAM   // (timing-only ablation: the strip operand is never fetched; the ring keeps whatever it holds)
+        asm volatile("" : "+v"(slot[0][0]), "+v"(slot[0][1]), "+v"(slot[1][0]), "+v"(slot[1][1]) : "s"(src));
+        return;
+#endif
         if constexpr (NP == 2) {
           asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %5, %6\n\t"
                        "global_load_dwordx4 %2, %4, %6 offset:1024\n\tglobal_load_dwordx4 %3, %5, %6 offset:1024"
@@ -407,11 +415,19 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         DP_STAMP(2);
         stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
+#ifdef STEIN_DP_ABL_NOEPI   // (timing-only ablation: no epilogue at all; the accumulators are kept alive)
+        const bool diag = false;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) asm volatile("" :: "v"(acc[ib][jb]));
+#else
 #define DP_RI(ib) ri[ib]
 #define DP_EPI_FAST
 #include "stein_dpanel_epilogue.inc"
 #undef DP_EPI_FAST
 #undef DP_RI
+#endif
         regular = !diag;
         if (window && sx.qn >= (u32)(DP_QCAP / 2)) { dp_flush(sx, spec, spec_buf, lane); regular = false; }
         request_norms(snext);                      // ("memory": the strip's stores are issued before this point)
