@@ -303,6 +303,9 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   u32x4 ring[DP_RING][2][3];
   f32x4g rj[2];
   float ri[8];
+#ifdef STEIN_DP_ABL_NOSTREAM
+  int abl_requests = 0;
+#endif
   DP_STAMP_DECL;
 
   for (; unit < U; unit += unit_step)
@@ -356,9 +359,13 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
       // a diagnostic build with more SGPR pressure sent its atomics to address 0).
       auto request = [&](const u16* sbase, int kt, u32x4 (&slot)[2][3]) {
         const u16* src = sbase + (size_t)(kt < ntk ? kt : ntk - 1) * 3 * XTILE_E;   // past the end: a harmless re-read keeps the counts
-#ifdef STEIN_DP_ABL_NOSTREAM   // (timing-only ablation: the strip operand is never fetched; the ring keeps whatever it holds)
-        asm volatile("" : "+v"(slot[0][0]), "+v"(slot[0][1]), "+v"(slot[1][0]), "+v"(slot[1][1]) : "s"(src));
-        return;
+#ifdef STEIN_DP_ABL_NOSTREAM   // (timing-only ablation: the strip operand is fetched for the wave's first eight k tiles only;
+        // after that the ring keeps those -- real -- values: MFMA power depends on the data, zeros would flatter it)
+        if (abl_requests >= 8) {
+          asm volatile("" : "+v"(slot[0][0]), "+v"(slot[0][1]), "+v"(slot[1][0]), "+v"(slot[1][1]) : "s"(src));
+          return;
+        }
+        ++abl_requests;
 #endif
         if constexpr (NP == 2) {
           asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %5, %6\n\t"
