@@ -103,6 +103,8 @@ __device__ __forceinline__ void dp_step(const unsigned char* pk /* panel k tile 
 struct DpWin {     // the speculative median window as a wave sees it
   u32 lo, width;   // raw bit patterns [lo, lo + width] of positive floats (width 0: no window)
   u32 below;       // weight of the entries below the window, this wave's strips so far (wave-uniform)
+  u32 below_lane;  // ... and, PER LANE, the number of such entries in the regular strips a windowed step counts with dp_count8
+                   // (each weighs `wt`; summed over the wave once, at the end of the kernel)
   u32 qn;          // entries in the wave's LDS queue (wave-uniform)
   u64* q;          // LDS, DP_QCAP entries of (key << 2 | weight)
   u32 over;        // the queue overflowed (-> SpecState::overflow: the window misses, the radix select runs)
@@ -144,16 +146,28 @@ __device__ __forceinline__ void dp_count4(DpWin& sx, const float (&v)[4], const 
 }
 
 // the eight values a lane holds of one 16-row block (two column blocks x four columns), every weight `wt`: the same
-// counting, one min-tree and one branch for all eight
+// counting with one min-tree and one branch for all eight, and the entries below the window counted PER LANE: a compare into
+// vcc and an add-with-carry (two VALU instructions per entry, no scalar ones).  The ballot form -- s_bcnt1 of eight 64-bit
+// masks per block -- left the compiler sixteen live SGPR pairs per block, which it parked in VGPR lanes: two v_writelane and
+// two v_readlane per ENTRY, ~800 VALU instructions per strip where ~300 do (round 4, found in the assembly; the epilogue of
+// one wave competes with the other wave's MFMAs for the SIMD's issue slots).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void dp_count8(DpWin& sx, const float (&v)[2][4], u32 wt, int lane) {
-  u32 mn = 0xffffffffu, cnt = 0u;
+  u32 mn = 0xffffffffu;
+  // (one statement: nothing for the compiler to pad or to reorder between a compare and its add)
+  asm("v_cmp_gt_i32 vcc, %9, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %4\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %5\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %6\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %7\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_gt_i32 vcc, %9, %8\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"   // signed compare of the raw bits: negative values are below too
+      : "+v"(sx.below_lane)
+      : "v"(v[0][0]), "v"(v[0][1]), "v"(v[0][2]), "v"(v[0][3]), "v"(v[1][0]), "v"(v[1][1]), "v"(v[1][2]), "v"(v[1][3]), "s"(sx.lo)
+      : "vcc");
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const u32 raw = __float_as_uint(v[k >> 2][k & 3]);
-    cnt += (u32)__popcll(__ballot((int)raw < (int)sx.lo));   // signed compare of the raw bits: negative values are below too
-    mn = min(mn, raw - sx.lo);
-  }
-  sx.below += cnt * wt;
+  for (int k = 0; k < 8; ++k) mn = min(mn, __float_as_uint(v[k >> 2][k & 3]) - sx.lo);
   if (__builtin_expect(__ballot(mn <= sx.width) != 0ull, 0)) {   // rare: a fraction of a percent of the blocks
 #pragma unroll
     for (int k = 0; k < 8; ++k) {   // (the offsets are formed again here: eight registers less across the hot path)
@@ -168,6 +182,13 @@ __device__ __forceinline__ void dp_count8(DpWin& sx, const float (&v)[2][4], u32
     }
     if (sx.qn > (u32)DP_QCAP) { sx.over = 1u; sx.qn = DP_QCAP; }
   }
+}
+// what the wave counted below the window: the wave-uniform part plus `wt` times the sum of the lanes' counters
+__device__ __forceinline__ u32 dp_below_total(const DpWin& sx, u32 wt) {
+  u32 c = sx.below_lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  return sx.below + c * wt;
 }
 
 // the wave's queue -> the global entry buffer (irregular: the caller must not assume a store count afterwards)
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   const float nts = -*two_s;
 
   DpWin sx;
-  sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u; sx.qn = 0u; sx.over = 0u;
+  sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u; sx.below_lane = 0u; sx.qn = 0u; sx.over = 0u;
   sx.q = reinterpret_cast<u64*>(smem + DP_PANEL + 8 * DP_STAGE + w * DP_QBYTES);
   bool window = false;
   if (spec) {
@@ -456,9 +477,10 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
   DP_HIST_FINISH
   if (window) {
     dp_flush(sx, spec, spec_buf, lane);
+    const u32 below = dp_below_total(sx, SYM ? 2u : 1u);
     if (lane == 0) {
-      if (sx.below) atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + ((blockIdx.x * 8 + w) % SPEC_SLOTS) * 8),
-                              (unsigned long long)sx.below);
+      if (below) atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + ((blockIdx.x * 8 + w) % SPEC_SLOTS) * 8),
+                           (unsigned long long)below);
       if (sx.over) spec->overflow = 1u;
     }
   }
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
   const float nts = -*two_s;
 
   DpWin sx;
-  sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u; sx.qn = 0u; sx.over = 0u;
+  sx.lo = 0xffffffffu; sx.width = 0u; sx.below = 0u; sx.below_lane = 0u; sx.qn = 0u; sx.over = 0u;
   sx.q = reinterpret_cast<u64*>(smem + DP_PANEL + 8 * DP_STAGE + w * DP_QBYTES);
   bool window = false;
   if (spec) {
@@ -621,9 +643,10 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel_deep(const u16
   DP_HIST_FINISH
   if (window) {
     dp_flush(sx, spec, spec_buf, lane);
+    const u32 below = dp_below_total(sx, SYM ? 2u : 1u);
     if (lane == 0) {
-      if (sx.below) atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + ((blockIdx.x * 8 + w) % SPEC_SLOTS) * 8),
-                              (unsigned long long)sx.below);
+      if (below) atomicAdd(reinterpret_cast<unsigned long long*>(spec_buf + ((blockIdx.x * 8 + w) % SPEC_SLOTS) * 8),
+                           (unsigned long long)below);
       if (sx.over) spec->overflow = 1u;
     }
   }
