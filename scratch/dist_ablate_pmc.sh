@@ -7,8 +7,8 @@ TAG=${1:-ablpmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for L in shipped lib_noepi.so lib_noepi_nostream.so lib_noepi_nopanel.so lib_mfmaonly.so; do
-  rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/$L -o x -- python3 $GRAFT_REPO_ROOT/scratch/dist_loop.py $L 16 > $OUT/$L.log 2>&1 || echo "$L refused" >&2
+for L in ${LIBS:-shipped lib_nostore.so lib_noepi.so lib_noepi_nostream.so lib_noepi_nopanel.so lib_mfmaonly.so}; do
+  rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/$L -o x -- python3 $GRAFT_REPO_ROOT/scratch/dist_loop.py $L 16 ${DL_ARGS:-} > $OUT/$L.log 2>&1 || echo "$L refused" >&2
 done
 python3 - <<PY
 import csv, glob, os, collections
