@@ -31,6 +31,11 @@
 #define STEIN_ABLATE_DPANEL
 #include "stein_ablate.h"   // DP_STAMP* / DP_STORE16: hooks of the diagnostic builds (nothing in the shipped library)
 
+#ifdef STEIN_DP_NOPRIO   // (A/B hook: the kernels without their issue priorities)
+#define DP_SETPRIO(p) do {} while (0)
+#else
+#define DP_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 constexpr int DP_THREADS = 512;        // 8 waves: two per SIMD
 constexpr int DP_RING = 4;             // k tiles of the strip operand in flight per wave
 constexpr int DP_PITCH = 144;          // bytes per staged row: 32 floats + 16 (conflict-free 16-byte writes down a column)
@@ -421,6 +426,12 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // In its k loop a wave outranks the wave of its SIMD that is in an epilogue: MFMAs and VALU instructions are issued
+        // through one port, the arbiter prefers the OLDER wave at equal priority, and an older wave in its epilogue -- a
+        // stream of VALU instructions, one every four cycles -- kept the younger one's MFMAs waiting: every epilogue
+        // instruction cost ~3 cycles of matrix-pipe time (counters, round 4: the pipe 0.63 busy with the epilogue, 0.86 without).
+        // With the ranks set, the epilogue's instructions fill the twelve free issue cycles behind each MFMA instead.
+        DP_SETPRIO(2);
         for (int g = 0; g < groups; ++g) {
           const bool last = g + 1 >= groups;
 #pragma unroll
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         // younger than they are (with more than one group of k tiles the loop's own waits have covered them already and
         // this one costs nothing)
         DP_STAMP(2);
+        DP_SETPRIO(0);
         stream_wait<DP_RING * LPS>();
         // ---- epilogue of the strip ----------------------------------------------------------------------------------------
 #ifdef STEIN_DP_ABL_NOEPI   // (timing-only ablation: no epilogue at all; the accumulators are kept alive)
