@@ -11,12 +11,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { F_NONE, F_IDLE_SLEEP, F_VALU_INDEP, F_VALU_CHAIN, F_PK_FMA, F_CMP_ADDC, F_SALU, F_LDS_RW, F_STORE, F_MIX, F_MFMA, F_FMA_MIX, F_EXP, F_CVT_PK, F_FMAAK, F_CVT_SDWA, F_DOT2, F_COUNT };
+enum { F_NONE, F_IDLE_SLEEP, F_VALU_INDEP, F_VALU_CHAIN, F_PK_FMA, F_CMP_ADDC, F_SALU, F_LDS_RW, F_STORE, F_MIX, F_MFMA, F_FMA_MIX, F_EXP, F_CVT_PK, F_FMAAK, F_CVT_SDWA, F_DOT2, F_LOAD, F_LOAD_STORE, F_COUNT };
 static const char* const NAMES[] = {"no second wave", "second wave sleeps", "v_fma_f32, 8 independent", "v_fma_f32, one chain",
                                     "v_pk_fma_f32, 8 independent", "v_cmp + v_addc chain", "s_add loop", "ds_write_b128 + ds_read_b128",
                                     "global_store_dwordx4 (1 KB)", "epilogue-like mix", "second wave issues MFMAs too", "v_fma_mix_f32, 8 independent",
                                     "v_exp_f32, 8 independent", "v_cvt_pk_f16_f32, 8 independent", "v_fmaak_f32, 8 independent",
-                                    "v_cvt_f32_f16 (sdwa word 1) + v_sub", "v_dot2_f32_f16, 8 independent"};
+                                    "v_cvt_f32_f16 (sdwa word 1) + v_sub", "v_dot2_f32_f16, 8 independent",
+                                    "global_load_dwordx4 (1 KB, L2 hits)", "2 loads + 1 store of 1 KB"};
 
 template <int FILL, int PRIO, int AIDLE>
 __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int iters) {
@@ -127,6 +128,23 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
         } else if (FILL == F_DOT2) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(x[i]) : "v"(y), "v"(z));
+        } else if (FILL == F_LOAD) {
+          // (eight 1 KB loads from a 64 KB region per wave that stays in the L2; waited for once per loop body)
+          f32x4 r[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(gp + ((rep * 8 + i) & 15) * 256));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] += r[i][0] * 1e-30f;
+        } else if (FILL == F_LOAD_STORE) {
+          f32x4 r[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(gp + ((rep * 4 + i) & 7) * 256));
+          *reinterpret_cast<float4*>(gp + 2048 + (rep & 3) * 256) = make_float4(x[0], x[1], x[2], x[3]);
+          *reinterpret_cast<float4*>(gp + 3072 + (rep & 3) * 256) = make_float4(x[4], x[5], x[6], x[7]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[i] += r[i][0] * 1e-30f;
         } else if (FILL == F_MFMA) {
           f16x8 a, b;
           for (int i = 0; i < 8; ++i) { a[i] = (_Float16)x[i]; b[i] = (_Float16)(x[i] * 0.5f); }
@@ -182,6 +200,7 @@ int main() {
   run<F_MIX, 0>(out, sink); run<F_MIX, 1>(out, sink);
   run<F_MFMA, 0>(out, sink);
   run<F_FMA_MIX, 0>(out, sink); run<F_EXP, 0>(out, sink); run<F_CVT_PK, 0>(out, sink); run<F_FMAAK, 0>(out, sink); run<F_CVT_SDWA, 0>(out, sink); run<F_DOT2, 0>(out, sink);
+  run<F_LOAD, 0>(out, sink); run<F_LOAD, 0, 1>(out, sink); run<F_LOAD_STORE, 0>(out, sink); run<F_LOAD_STORE, 0, 1>(out, sink);
   run<F_FMA_MIX, 0, 1>(out, sink); run<F_EXP, 0, 1>(out, sink); run<F_CVT_PK, 0, 1>(out, sink); run<F_FMAAK, 0, 1>(out, sink); run<F_CVT_SDWA, 0, 1>(out, sink); run<F_DOT2, 0, 1>(out, sink);
   run<F_VALU_INDEP, 0, 1>(out, sink); run<F_VALU_CHAIN, 0, 1>(out, sink); run<F_PK_FMA, 0, 1>(out, sink); run<F_CMP_ADDC, 0, 1>(out, sink);
   run<F_LDS_RW, 0, 1>(out, sink); run<F_STORE, 0, 1>(out, sink); run<F_MIX, 0, 1>(out, sink); run<F_MFMA, 0, 1>(out, sink);
