@@ -184,7 +184,7 @@ class NumpyStages:
         if lo is None:                                       # the radix passes produced the median: its lower target
             lo = key_to_f32(st.prefix[0])
         key = int(f32_keys(np.float32(lo)).reshape(-1)[0])
-        hw, nxt = 4096, key
+        hw, nxt, earned = 4096, key, 0
         if sp["magic"] in (1, 2):
             pred = np.float32(2) * np.float32(lo) - key_to_f32(sp["last_key"])
             c = int(f32_keys(pred if pred == pred else np.float32(lo)).reshape(-1)[0])
@@ -192,12 +192,14 @@ class NumpyStages:
             if sp["magic"] == 2 and sp["width"] != 0:
                 err = abs(key - sp["center"])
                 hw = self.HW_MAX if err > self.HW_MAX // 4 else 4 * err + 48
+                hw = max(hw, sp.get("earned_hw", 0) - sp.get("earned_hw", 0) // 4)   # never below 3/4 of the last earned width
+                earned = hw
                 if sp["hit"] and sp["count"] > ((1 << 21) - 2048) // 2 and hw > sp["halfwidth"] // 2:
                     hw = sp["halfwidth"] // 2 + 1
             sp["magic"] = 2
         else:
             sp["magic"] = 1
-        sp.update(last_key=key, center=nxt, halfwidth=min(hw, self.HW_MAX))
+        sp.update(last_key=key, center=nxt, halfwidth=min(hw, self.HW_MAX), earned_hw=min(earned, self.HW_MAX))
 
     def median_hist_pass(self, D, ld, n_local, n, level, sel, hist, symmetric=False):
         hist_pass(D.numpy()[:n_local, :n], level, self._st, hist.numpy()[level])

@@ -121,7 +121,8 @@ struct SpecState {
                   // replaces it by the sum over the ranks
   u32 overflow;   // a workgroup's LDS queue overflowed
   u32 hit;        // this step's median came from the window; the radix-select passes skip themselves
-  u64 reserved;   // (the weight below the window is summed from the slots at the head of the buffer)
+  u32 earned_hw;  // the last half-width that came from a measured prediction error (0: none yet): the floor of the next one
+  u32 reserved;   // (the weight below the window is summed from the slots at the head of the buffer)
   u64 total;      // n * n
   u32 last_key;   // key of the previous step's lower median target
   u32 skip_l0;    // the level-0 histogram pass over D is not needed (taken in the distance epilogue, or the window hit)

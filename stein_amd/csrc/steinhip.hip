@@ -873,7 +873,7 @@ __global__ __launch_bounds__(1024) void k_spec_pick(SelState* st, SpecState* sp,
 __device__ __attribute__((noinline)) void spec_update_dev(const SelState* st, SpecState* sp) {
   const u32 key = f32_key(st->lo);
   const bool had_window = sp->width != 0u;
-  u32 hw = 4096u, next = key;
+  u32 hw = 4096u, next = key, earned = 0u;
   if (sp->magic == SPEC_MAGIC1 || sp->magic == SPEC_MAGIC2) {
     // linear extrapolation of the VALUE (key space bends at every power of two)
     const float pred = 2.f * st->lo - key_f32(sp->last_key);
@@ -883,6 +883,14 @@ __device__ __attribute__((noinline)) void spec_update_dev(const SelState* st, Sp
     if (sp->magic == SPEC_MAGIC2 && had_window) {   // the window of this step was centred on a real prediction
       const u32 err = key > sp->center ? key - sp->center : sp->center - key;
       hw = err > SPEC_HW_MAX / 4u ? SPEC_HW_MAX : 4u * err + 48u;
+      // ... and never below three quarters of the previous one: one lucky prediction (an error of a few keys) used to shrink
+      // the window to ~60 keys and the next ordinary error missed it -- 10 % misses under noisy scores and at n = 4096 in
+      // bf16; with the floor 1 %, for a window a third wider on average (scratch/window_policy.py replays the rules on
+      // recorded runs: profiles/r04_window_policy.txt).  A miss costs a radix select, a wider window a few more entries.
+      // (the floor follows EARNED widths only: the 4096-key window of a predictor without a velocity is not one)
+      const u32 floor_hw = sp->earned_hw - sp->earned_hw / 4u;
+      if (hw < floor_hw) hw = floor_hw;
+      earned = hw;
       if (sp->hit && sp->count > SPEC_CAP / 2 && hw > sp->halfwidth / 2u) hw = sp->halfwidth / 2u + 1u;   // keep the buffer small
     }
     sp->magic = SPEC_MAGIC2;
@@ -896,6 +904,7 @@ __device__ __attribute__((noinline)) void spec_update_dev(const SelState* st, Sp
   sp->last_key = key;
   sp->center = next;
   sp->halfwidth = hw > SPEC_HW_MAX ? SPEC_HW_MAX : hw;
+  sp->earned_hw = earned > SPEC_HW_MAX ? SPEC_HW_MAX : earned;
 }
 __global__ void k_spec_update(const SelState* st, SpecState* sp) {
   if (threadIdx.x || blockIdx.x) return;
