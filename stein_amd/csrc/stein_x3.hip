@@ -506,8 +506,20 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
   // deterministically.)
   const int nstage = (ntile + FS_KT - 1) / FS_KT;
   const int rot = (cb % FS_KT) * (cblocks >= FS_KT ? 1 : FS_KT / cblocks) % FS_KT;
+  // Visit order of the STAGES (upper, one workgroup per row tile and column block over the whole j range, a power-of-two number
+  // of row tiles): stage v of the row tiles that share an XCD (`group` consecutive ones: 32 logical ids / cblocks) is the
+  // 128-column block v ^ (tile_m & ~(group - 1)).  Every stored tile D[I][J] is read twice, by row tile I as itself and by
+  // row tile J as its mirror image; in the plain order 0, 1, 2 ... the two reads lie |I - J| stages apart (43 on average,
+  // 16 MB of D traffic per stage: the second read comes from HBM again), in this order |I % group - J % group| < group
+  // stages apart (5 on average), where the memory-side cache still holds the tile.  The row tiles of an XCD keep walking the
+  // SAME block at the same time, so V is shared in their L2 as before.
+  const int group = cblocks <= 32 ? 32 / cblocks : 1;
+  const bool permute = RB == 8 && upper != 0 && jbeg == 0 && jend == n && (cblocks & (cblocks - 1)) == 0 && cblocks <= 4 &&
+                       nstage * FS_KT == ntile && (nstage & (nstage - 1)) == 0 && nstage == tiles_m && nstage >= 2 * group;
+  const int xmask = permute ? (tile_m & ~(group - 1)) : 0;
+  auto stage_of = [&](int v) { return v ^ xmask; };   // (v = nstage, "the stage after the last", stays out of range)
   auto tile_at = [&](int stage, int u) {     // u may run past the stage: u >= FS_KT continues in the next stage
-    const int st2 = stage + u / FS_KT, u2 = u % FS_KT;
+    const int st2 = stage_of(stage + u / FS_KT), u2 = u % FS_KT;
     return st2 * FS_KT + ((st2 + 1) * FS_KT <= ntile ? ((u2 + rot) & (FS_KT - 1)) : u2);
   };
 
@@ -697,10 +709,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_phi_x3fs(const float* __restrict
     // parity picks the register set (X even, Y odd); a tile's loads are issued two tiles ahead, right after the set is free.
 #pragma unroll
     for (int u = 0; u < PD; ++u)
-      if (tile_at(0, u) < ntile) request(jt(tile_at(0, u)), 0 < ntr, rd[u]);
+      if (tile_at(0, u) < ntile) request(jt(tile_at(0, u)), stage_of(0) < ntr, rd[u]);
     // stage st: turn the registers of its tiles into LDS data (slot u <- tile_at(st, u)), then request the next stage's
     auto produce_stage = [&](int st, unsigned char* buf) {
-      const bool tr_now = st < ntr, tr_next = st + 1 < ntr;   // workgroup-uniform
+      const bool tr_now = stage_of(st) < ntr, tr_next = stage_of(st + 1) < ntr;   // workgroup-uniform
 #pragma unroll
       for (int u = 0; u < FS_KT; ++u) {
         const int tile_u = tile_at(st, u), next_u = tile_at(st + 1, u);
