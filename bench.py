@@ -26,7 +26,9 @@ on), `frac` = achieved / peak (= `frac_algorithmic`).  The split path executes 3
 reach at most); the strict fp32-input MFMA kernels are timed under `fp32_path`.
 
 wall_minus_events_ms (every timed entry): wall time per step minus the GPU time the HIP events of the same steps bracket;
-`host_stall_suspected` when the gap exceeds max(0.05 ms, 25 %).  A stalled timed loop (headline or variant) is timed once more (`retimed` keeps the first run).
+`host_stall_suspected` when the gap exceeds max(0.03 ms, 4 %) (a healthy C3 loop shows 0.012 ms).  A stalled timed loop
+(headline or variant) is timed again, at most twice; the line carries the run with the smallest wall time and `retimed` lists
+what the other runs measured -- every one of them is a complete timed loop of the requested number of steps.
 
 window: the headline step uses the speculative median window (exact, stein_common.h); `window` reports how many of the
 timed steps it delivered the median, and `miss_path` times the same steps with the window disabled (every step pays the
@@ -105,7 +107,7 @@ def gap_fields(wall_ms, events_ms):
         return {"events_ms": None, "wall_minus_events_ms": None, "host_stall_suspected": None}
     gap = wall_ms - events_ms
     return {"events_ms": round(events_ms, 4), "wall_minus_events_ms": round(gap, 4),
-            "host_stall_suspected": bool(gap > max(0.05, 0.25 * events_ms))}
+            "host_stall_suspected": bool(gap > max(0.03, 0.04 * events_ms))}
 
 
 def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
@@ -234,16 +236,25 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
 
 
 def run_stable(torch, dist, wl, device, rank, world, group, steps, warmup, **kw):
-    """run_workload, timed once more when the host, not the GPU, set the pace of the timed loop (one rank: wall time per step
-    beyond the event-bracketed GPU time by more than max(0.05 ms, 25 %)).  -> (result, None | what the first run measured)"""
+    """run_workload, timed again (at most twice) when the host, not the GPU, set the pace of the timed loop (one rank: wall time
+    per step beyond the event-bracketed GPU time by more than max(0.03 ms, 4 %): a launch thread that lost its core on a shared
+    box).  Keeps the run with the smallest wall time.  -> (result, None | what the other runs measured)"""
     res = run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, **kw)
-    if world != 1 or not gap_fields(res["elapsed"] / steps * 1e3, res["events_ms"])["host_stall_suspected"]:
+    stalled = lambda r: gap_fields(r["elapsed"] / steps * 1e3, r["events_ms"])["host_stall_suspected"]
+    if world != 1 or not stalled(res):
         return res, None
-    first = {"why": "wall time per step exceeded the event-bracketed GPU time by more than max(0.05 ms, 25 %): host stall; timed once more",
-             "first_run_ms_per_step": res["elapsed"] / steps * 1e3, "first_run_events_ms": res["events_ms"]}
-    del res
-    torch.cuda.empty_cache()
-    return run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, **kw), first
+    others = []
+    for _ in range(2):
+        again = run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, **kw)
+        keep, drop = (again, res) if again["elapsed"] < res["elapsed"] else (res, again)
+        others.append({"ms_per_step": drop["elapsed"] / steps * 1e3, "events_ms": drop["events_ms"]})
+        res = keep
+        del drop, again
+        torch.cuda.empty_cache()
+        if not stalled(res):
+            break
+    return res, {"why": "wall time per step exceeded the event-bracketed GPU time by more than max(0.03 ms, 4 %): host stall; "
+                        "timed again, the run with the smallest wall time is reported", "other_runs": others}
 
 
 def crosscheck_comms(torch, dist, wl, device, rank, world, group, steps=4):

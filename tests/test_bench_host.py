@@ -14,6 +14,8 @@ def test_gap_fields_flag_a_host_stall():
     assert stalled["host_stall_suspected"] is True and abs(stalled["wall_minus_events_ms"] - 6.06) < 1e-9
     small = bench.gap_fields(0.029, 0.025)                    # C1: a few microseconds of launch gaps are not a stall
     assert small["host_stall_suspected"] is False
+    hiccup = bench.gap_fields(1.0824, 0.9747)                 # round 4: one ~2 ms hiccup of the launch thread in a 20-step loop
+    assert hiccup["host_stall_suspected"] is True
     assert bench.gap_fields(0.45, None) == {"events_ms": None, "wall_minus_events_ms": None, "host_stall_suspected": None}
 
 
