@@ -609,12 +609,15 @@ __device__ __attribute__((noinline)) void spec_update_dev(const SelState* st, Sp
 
 // All 256 bins of an LDS histogram -> the bin holding 0-based rank `rank` and the rank inside it; *bin = 256 when the
 // rank lies past the last bin.  Called by the whole workgroup (>= 256 threads); `scan` is 256 words of LDS scratch.
-__device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u32* bin, u32* rest) {
-  // the first four waves scan 64 bins each with shuffles; `scan[0..3]` carries the wave totals (3 barriers in all)
+// Both targets at once: waves 0-3 scan histogram hA (256 bins) for rankA, waves 4-7 histogram hB for rankB, each with
+// shuffles; `scan[0..7]` carries the wave totals (2 barriers in all; round 4: four separate locates cost 12 of them, ~1.4 k
+// cycles each time, a quarter of this one-workgroup kernel).  bin[k] = 256: rank k lies beyond its histogram.
+__device__ __forceinline__ void spec_locate2(const u32* hA, u32 rankA, const u32* hB, u32 rankB, u32* scan, u32* bin, u32* rest) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int side = t >> 8;                       // 0: target A (threads 0..255), 1: target B (256..511)
   u32 c = 0u, incl = 0u;
-  if (t < 256) {
-    c = h[t];
+  if (t < 512) {
+    c = (side ? hB : hA)[t & 255];
     incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -623,13 +626,13 @@ __device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u
     }
     if (lane == 63) scan[wave] = incl;
   }
-  if (t == 0) *bin = 256u;
+  if (t < 2) bin[t] = 256u;
   __syncthreads();
-  if (t < 256) {
+  if (t < 512) {
     u32 base = 0u;
-    for (int w = 0; w < wave; ++w) base += scan[w];
-    const u32 excl = base + incl - c;
-    if (excl <= rank && rank < excl + c) { *bin = (u32)t; *rest = rank - excl; }
+    for (int w = side * 4; w < wave; ++w) base += scan[w];
+    const u32 excl = base + incl - c, rank = side ? rankB : rankA;
+    if (excl <= rank && rank < excl + c) { bin[side] = (u32)(t & 255); rest[side] = rank - excl; }
   }
   __syncthreads();
 }
@@ -637,6 +640,13 @@ __device__ __forceinline__ void spec_locate(const u32* h, u32 rank, u32* scan, u
 // One workgroup: exact weighted selection of the two median targets among the buffered window entries.
 // Entry = key << 2 | weight, offset o = key - lo_key < 65536: pass 1 histograms o >> 8, pass 2 the low byte of the
 // entries that share each target's high byte.  Returns (workgroup-uniform) whether the window held both targets.
+#ifdef STEIN_SEL_STAMPS
+__device__ unsigned long long g_sel_stamps[16];
+extern "C" int stein_debug_sel_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sel_stamps), sizeof(g_sel_stamps)) == hipSuccess ? 0 : -1; }
+#define SEL_STAMP(k) do { if (threadIdx.x == 0) { g_sel_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } } while (0)
+#else
+#define SEL_STAMP(k) do {} while (0)
+#endif
 __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, const u64* __restrict__ slots, float ln_n,
                                                  float* h2_out, int update) {
   const u64* __restrict__ buf = slots + SPEC_SLOTS * 8;
@@ -644,24 +654,42 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
   __shared__ u32 sel[8];   // [0,1] high bytes, [2,3] ranks inside them, [4,5] low bytes, [6,7] scratch
   __shared__ u64 below_s;
   const int t = threadIdx.x;
-  const u32 cnt = sp->count, lo = sp->lo_key;
-  if (sp->width == 0u || sp->overflow || cnt > SPEC_CAP || cnt == 0u) return false;   // miss: the radix select runs
+  SEL_STAMP(0);
+  const u32 cnt = sp->count, lo = sp->lo_key, width = sp->width;
+  if (width == 0u || sp->overflow || cnt > SPEC_CAP || cnt == 0u) return false;   // miss: the radix select runs
+  SEL_STAMP(1);
+  // thread 0 asks now for what it will need at the very end (the result and the predictor update are a chain of dependent
+  // loads otherwise: ~3 k cycles behind the last barrier)
+  u32 even0 = 0u;
+  if (t == 0) even0 = st->even;
+  u64 mine = t < (int)SPEC_SLOTS ? slots[t * 8] : 0ull;
+  const u64 total = sp->total;
   if (t == 0) below_s = 0ull;
   if (t < 256) { h1[t] = 0u; h2a[t] = 0u; h2b[t] = 0u; }
   __syncthreads();
-  if (t < (int)SPEC_SLOTS && slots[t * 8])
-    atomicAdd(reinterpret_cast<unsigned long long*>(&below_s), (unsigned long long)slots[t * 8]);
+  {
+    // the weights below the window, one slot per thread: summed per wave first (256 same-address 64-bit LDS atomics took
+    // 7 k cycles of this kernel's 28 k at C2)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((t & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long*>(&below_s), (unsigned long long)mine);
+  }
   __syncthreads();
-  const u64 total = sp->total, below = below_s;
+  const u64 below = below_s;
+  SEL_STAMP(2);
   const u64 r0 = (total & 1ull) ? total / 2 : total / 2 - 1, r1 = total / 2;
   if (r0 < below || r1 - below > 0xfffffff0ull) return false;   // the target lies below the window
-  // A window narrower than 256 keys puts EVERY entry into one or two bins of this pass: 2*10^4 same-address LDS atomics
-  // were ~10 us of this one-workgroup kernel.  Lanes that share the leader's bin are merged into one atomic per wave
-  // (hist_add; the weights are 1 or 2, one call each).
-  // Up to 16 entries per thread are fetched ONCE, all loads in flight together, and both passes work from the registers
-  // (round 4: the loops below paid one memory latency per 1024 entries, twice -- 10.8 of C2's 102 us, 17 us at C3).
+  // Pass 1 histograms the HIGH byte of the offsets: a window of `width` keys occupies (width >> 8) + 1 bins, a handful, and
+  // every entry of every wave lands in them.  Up to 16 entries per thread are fetched ONCE, all loads in flight together,
+  // and both passes work from the registers (round 4: the loops below paid one memory latency per 1024 entries, twice).
+  // With at most eight bins in play the counts are kept in eight registers per thread, summed over the wave with shuffles
+  // and added with one atomic per wave and bin (LDS atomics merged by ballots, below, were 1 k cycles per 1024 entries:
+  // 7 k of this kernel's 28 k cycles at C2, 15 k of 39 k at C3).
+  // (the 8-byte entries come through ONE compute unit: 13 k of them are 108 KB, ~3 k cycles of its load path -- requested
+  // any earlier they only delay the slot sums above, which wait behind them in the memory pipeline)
   constexpr int EPT = 16;
   const bool inreg = cnt <= 1024u * EPT;
+  const u32 nb = (width >> 8) + 1u;
   u64 er[EPT];
   if (inreg) {
 #pragma unroll
@@ -669,12 +697,34 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
       const u32 i = (u32)k * 1024u + (u32)t;
       er[k] = (u32)k * 1024u < cnt && i < cnt ? buf[i] : 0ull;   // (0: weight 0, counted nowhere)
     }
+  }
+  if (inreg && nb <= 8u) {
+    u32 c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if ((u32)k * 1024u < cnt) {                // workgroup-uniform
+        const u64 e = er[k];
+        const u32 hb = (((u32)(e >> 2) - lo) >> 8) & 255u, w = (u32)e & 3u;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) c[b] += hb == (u32)b ? w : 0u;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if ((u32)b < nb) {                         // workgroup-uniform
+        u32 v = c[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((t & 63) == 0 && v) atomicAdd(&h1[b], v);
+      }
+    }
+  } else if (inreg) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       if ((u32)k * 1024u < cnt) {                // workgroup-uniform: the ballots need every lane of a wave
         const u64 e = er[k];
         const u32 hb = (((u32)(e >> 2) - lo) >> 8) & 255u, w = (u32)e & 3u;
-        hist_add(h1, hb, w == 2u, t & 63, 2u);
+        hist_add(h1, hb, w == 2u, t & 63, 2u);   // (lanes that share the leader's bin are merged into one atomic per wave)
         hist_add(h1, hb, w == 1u, t & 63, 1u);
         if (w == 3u) atomicAdd(&h1[hb], 3u);     // (no producer writes weight 3; kept exact all the same)
       }
@@ -691,17 +741,20 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
     }
   }
   __syncthreads();
-  spec_locate(h1, (u32)(r0 - below), scan, &sel[0], &sel[2]);
-  spec_locate(h1, (u32)(r1 - below), scan, &sel[1], &sel[3]);
+  SEL_STAMP(3);
+  spec_locate2(h1, (u32)(r0 - below), h1, (u32)(r1 - below), scan, &sel[0], &sel[2]);
+  SEL_STAMP(4);
   const u32 ba = sel[0], bb = sel[1];
   if (ba == 256u || bb == 256u) return false;   // a target lies above the window
   if (inreg) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const u64 e = er[k];
-      const u32 o = (u32)(e >> 2) - lo, w = (u32)e & 3u;
-      if (w && (o >> 8) == ba) atomicAdd(&h2a[o & 255u], w);
-      if (w && (o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
+      if ((u32)k * 1024u < cnt) {                // workgroup-uniform
+        const u64 e = er[k];
+        const u32 o = (u32)(e >> 2) - lo, w = (u32)e & 3u;
+        if (w && (o >> 8) == ba) atomicAdd(&h2a[o & 255u], w);
+        if (w && (o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
+      }
     }
   } else {
     for (u32 i = t; i < cnt; i += 1024) {
@@ -712,11 +765,12 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
     }
   }
   __syncthreads();
-  spec_locate(h2a, sel[2], scan, &sel[4], &sel[6]);
-  spec_locate(h2b, sel[3], scan, &sel[5], &sel[7]);
+  SEL_STAMP(5);
+  spec_locate2(h2a, sel[2], h2b, sel[3], scan, &sel[4], &sel[6]);
+  SEL_STAMP(6);
   if (t == 0) {
     const float flo = key_f32(lo + ((ba << 8) | sel[4])), fhi = key_f32(lo + ((bb << 8) | sel[5]));
-    const float med = st->even ? 0.5f * (flo + fhi) : flo;
+    const float med = even0 ? 0.5f * (flo + fhi) : flo;
     const float bw = sqrtf(med / ln_n);      // abstract_kernel.py:40
     const float h2 = bw * bw;                // squared_exponential_kernel.py:22 squares it again
     st->lo = flo; st->hi = fhi; st->median = med; st->h2 = h2;
@@ -724,6 +778,7 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
     sp->hit = 1u;
     sp->skip_l0 = 1u;
     if (update) spec_update_dev(st, sp);   // fused call: no separate k_spec_update launch
+    SEL_STAMP(7);
   }
   return true;
 }
