@@ -746,6 +746,7 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
   SEL_STAMP(4);
   const u32 ba = sel[0], bb = sel[1];
   if (ba == 256u || bb == 256u) return false;   // a target lies above the window
+  const bool two_hb = ba != bb;                 // (both targets in one high byte, the usual case: one low-byte histogram serves both)
   if (inreg) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -753,7 +754,7 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
         const u64 e = er[k];
         const u32 o = (u32)(e >> 2) - lo, w = (u32)e & 3u;
         if (w && (o >> 8) == ba) atomicAdd(&h2a[o & 255u], w);
-        if (w && (o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
+        if (w && two_hb && (o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
       }
     }
   } else {
@@ -761,12 +762,12 @@ __device__ __forceinline__ bool spec_select_body(SelState* st, SpecState* sp, co
       const u64 e = buf[i];
       const u32 o = (u32)(e >> 2) - lo, w = (u32)e & 3u;
       if ((o >> 8) == ba) atomicAdd(&h2a[o & 255u], w);
-      if ((o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
+      if (two_hb && (o >> 8) == bb) atomicAdd(&h2b[o & 255u], w);
     }
   }
   __syncthreads();
   SEL_STAMP(5);
-  spec_locate2(h2a, sel[2], h2b, sel[3], scan, &sel[4], &sel[6]);
+  spec_locate2(h2a, sel[2], two_hb ? h2b : h2a, sel[3], scan, &sel[4], &sel[6]);
   SEL_STAMP(6);
   if (t == 0) {
     const float flo = key_f32(lo + ((ba << 8) | sel[4])), fhi = key_f32(lo + ((bb << 8) | sel[5]));
