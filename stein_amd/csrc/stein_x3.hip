@@ -60,6 +60,7 @@
 constexpr int PEXP_H2 = 14;   // KIND 2: P = exp2(c D + 14), in (0, 2^14] (fp16 normal range down to P = 2^-28)
 template <int KIND> struct SplitTraits { static constexpr int pexp = KIND == 2 ? PEXP_H2 : 0; };
 
+#include <type_traits>
 #define STEIN_ABLATE_X3
 #include "stein_ablate.h"   // STAMP / X3_STAMP_*: phase-stamp hooks of the diagnostic builds (nothing in the shipped library)
 
@@ -154,33 +155,68 @@ __device__ __forceinline__ void make_scales_body(const u32* cmax, int dc, float*
 // blockIdx.z = 0: X0 -> cmax[0, dc), 1: X1 -> cmax[dc, 2 dc)
 // done != NULL (fused call: both matrices given, completion counters zeroed by the prologue): the last workgroup to finish
 // also turns the maxima into the scales, which saves the k_make_scales launch (round 4: a two-level count, so whatever the grid).
-template <typename TIN>
-__global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
-                                                u32* __restrict__ cmax0, int dc, int zbase, float* __restrict__ sc,
-                                                int pexp, HistSync* done) {
+// V4 (fp32, d % 4 == 0, 16-byte aligned rows; 1024 threads): a lane reads four columns at once, so a wave's load is one full
+// KB of a row instead of 256 bytes, sixteen waves walk sixteen rows at a time, and the workgroup's maxima are added by 256
+// threads, one column each (coalesced atomics, and a quarter as many per column as with 256-thread workgroups: the
+// same-address atomic chains were the larger part of the 4-byte form's 14-16 us at C3).
+template <typename TIN, bool V4>
+__global__ __launch_bounds__(V4 ? 1024 : 256) void k_colmax(const TIN* __restrict__ X0, const TIN* __restrict__ X1, int n, int d,
+                                                            u32* __restrict__ cmax0, int dc, int zbase, float* __restrict__ sc,
+                                                            int pexp, HistSync* done) {
   const int z = blockIdx.z + zbase;
   const TIN* __restrict__ X = z ? X1 : X0;
   u32* __restrict__ cmax = cmax0 + (z ? dc : 0);
-  __shared__ u32 red[4][64];
+  constexpr int CW = V4 ? 4 : 1;                 // columns per lane
+  constexpr int NW = V4 ? 16 : 4;                // waves = rows in flight per workgroup
+  __shared__ u32 red[NW][64 * CW];
   const int t = threadIdx.x, cx = t & 63, ry = t >> 6;
-  const int col = blockIdx.x * 64 + cx;
-  u32 m = 0u;
+  const int col = (blockIdx.x * 64 + cx) * CW;
+  u32 m[CW];
+#pragma unroll
+  for (int e = 0; e < CW; ++e) m[e] = 0u;
   if (col < d) {
     // four independent loads in flight per lane (one dependent load at a time read the matrices at 2 TB/s)
-    const long step = (long)gridDim.y * 4;
-    long r = (long)blockIdx.y * 4 + ry;
-    u32 m1 = 0u, m2 = 0u, m3 = 0u;
-    for (; r + 3 * step < n; r += 4 * step) {
-      const u32 a0 = abs_bits(X[(size_t)r * d + col]), a1 = abs_bits(X[(size_t)(r + step) * d + col]);
-      const u32 a2 = abs_bits(X[(size_t)(r + 2 * step) * d + col]), a3 = abs_bits(X[(size_t)(r + 3 * step) * d + col]);
-      m = max(m, a0); m1 = max(m1, a1); m2 = max(m2, a2); m3 = max(m3, a3);
+    const long step = (long)gridDim.y * NW;
+    long r = (long)blockIdx.y * NW + ry;
+    if constexpr (V4) {
+      if constexpr (std::is_same<TIN, float>::value) {
+        u32 m1[4] = {0u, 0u, 0u, 0u}, m2[4] = {0u, 0u, 0u, 0u}, m3[4] = {0u, 0u, 0u, 0u};
+        auto ld = [&](long row) { return *reinterpret_cast<const float4*>(X + (size_t)row * d + col); };
+        auto up = [&](u32 (&acc)[4], const float4& v) {
+          acc[0] = max(acc[0], abs_bits(v.x)); acc[1] = max(acc[1], abs_bits(v.y));
+          acc[2] = max(acc[2], abs_bits(v.z)); acc[3] = max(acc[3], abs_bits(v.w));
+        };
+        for (; r + 3 * step < n; r += 4 * step) {
+          const float4 a0 = ld(r), a1 = ld(r + step), a2 = ld(r + 2 * step), a3 = ld(r + 3 * step);
+          up(m, a0); up(m1, a1); up(m2, a2); up(m3, a3);
+        }
+        for (; r < n; r += step) { const float4 a0 = ld(r); up(m, a0); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = max(max(m[e], m1[e]), max(m2[e], m3[e]));
+      }
+    } else {
+      u32 m1 = 0u, m2 = 0u, m3 = 0u;
+      for (; r + 3 * step < n; r += 4 * step) {
+        const u32 a0 = abs_bits(X[(size_t)r * d + col]), a1 = abs_bits(X[(size_t)(r + step) * d + col]);
+        const u32 a2 = abs_bits(X[(size_t)(r + 2 * step) * d + col]), a3 = abs_bits(X[(size_t)(r + 3 * step) * d + col]);
+        m[0] = max(m[0], a0); m1 = max(m1, a1); m2 = max(m2, a2); m3 = max(m3, a3);
+      }
+      for (; r < n; r += step) m[0] = max(m[0], abs_bits(X[(size_t)r * d + col]));
+      m[0] = max(max(m[0], m1), max(m2, m3));
     }
-    for (; r < n; r += step) m = max(m, abs_bits(X[(size_t)r * d + col]));
-    m = max(max(m, m1), max(m2, m3));
   }
-  red[ry][cx] = m;
+#pragma unroll
+  for (int e = 0; e < CW; ++e) red[ry][cx * CW + e] = m[e];
   __syncthreads();
-  if (ry == 0 && col < d) atomicMax(&cmax[col], max(max(red[0][cx], red[1][cx]), max(red[2][cx], red[3][cx])));
+  if (t < 64 * CW) {                             // one thread per column of the workgroup's span
+    const int c = blockIdx.x * 64 * CW + t;
+    if (c < d) {
+      u32 v = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v = max(v, red[w][t]);
+      atomicMax(&cmax[c], v);
+    }
+  }
   if (done) {
     __shared__ u32 s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's maxima have been acknowledged
@@ -190,7 +226,7 @@ __global__ __launch_bounds__(256) void k_colmax(const TIN* __restrict__ X0, cons
       s_last = tree_report_done(done->cm_leaf, &done->cm_top, id, gridDim.x * gridDim.y * gridDim.z) ? 1u : 0u;
     }
     __syncthreads();
-    if (s_last) make_scales_body(cmax0, dc, sc, pexp, 1, &red[0][0]);
+    if (s_last) make_scales_body(cmax0, dc, sc, pexp, 1, &red[0][0]);   // (written for 256 threads; more of them repeat columns: same values)
   }
 }
 
@@ -932,9 +968,17 @@ int stein_x3_split(const void* theta_all, const void* score_all, int dtype, int6
     if (!fuse_done) HIP_TRY(hipMemsetAsync(cmax + (size_t)zbase * dc, 0, (size_t)nz * dc * sizeof(u32), stream));
     int gy = (int)((n + 63) / 64);
     if (gy > 256) gy = 256;
-    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, nz);
-    hipLaunchKernelGGL(k_colmax<float>, grid, dim3(256), 0, stream, (const float*)score_all, (const float*)theta_all,
-                       (int)n, (int)d, cmax, dc, zbase, sc, PEXP_H2, fuse_done);
+    const bool v4 = d % 4 == 0 && (!score_all || ((uintptr_t)score_all & 15) == 0) && (!theta_all || ((uintptr_t)theta_all & 15) == 0);
+    if (v4) {
+      const int gy4 = gy > 64 ? 64 : gy;
+      const dim3 grid((unsigned)((d + 255) / 256), (unsigned)gy4, nz);
+      hipLaunchKernelGGL((k_colmax<float, true>), grid, dim3(1024), 0, stream, (const float*)score_all, (const float*)theta_all,
+                         (int)n, (int)d, cmax, dc, zbase, sc, PEXP_H2, fuse_done);
+    } else {
+      const dim3 grid((unsigned)((d + 63) / 64), (unsigned)gy, nz);
+      hipLaunchKernelGGL((k_colmax<float, false>), grid, dim3(256), 0, stream, (const float*)score_all, (const float*)theta_all,
+                         (int)n, (int)d, cmax, dc, zbase, sc, PEXP_H2, fuse_done);
+    }
     LAUNCH_CHECK("k_colmax");
   }
   if ((kind != 2 && !scales_written) || (kind == 2 && !fuse_done)) {
