@@ -218,3 +218,26 @@ def test_unaligned_outputs_take_the_scalar_paths(cuda):
     apply(th_u, phi_ref, hi_u)
     torch.cuda.synchronize()
     assert torch.equal(th_a, th_u) and torch.equal(hi_a, hi_u)
+
+
+@pytest.mark.gpu
+def test_column_maxima_paths_agree(cuda):
+    """The operand scales come from column maxima taken with 16-byte loads when d % 4 == 0 and the inputs are 16-byte
+    aligned, else four bytes at a time: the same inputs 4 bytes past a 16-byte boundary must give byte-identical planes."""
+    n, d = 1500, 256
+    T64, G64 = _inputs(n, d, seed=12, scale=3.0)
+    T = torch.tensor(T64, dtype=torch.float32, device=cuda)
+    G = torch.tensor(G64 * 1e-3, dtype=torch.float32, device=cuda)
+    eng = SvgdEngine(n, d, device=cuda, x3=True, small=False)
+    st = eng.stages
+    st.x3_prepare(T, G, n, d, eng.planes)
+    torch.cuda.synchronize()
+    aligned = eng.planes.clone()
+    tb, gb = torch.zeros(n * d + 1, device=cuda), torch.zeros(n * d + 1, device=cuda)
+    T_un, G_un = tb[1:].view(n, d), gb[1:].view(n, d)
+    T_un.copy_(T); G_un.copy_(G)
+    assert T_un.data_ptr() % 16 == 4 and G_un.data_ptr() % 16 == 4
+    eng.planes.zero_()
+    st.x3_prepare(T_un, G_un, n, d, eng.planes)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.planes, aligned)
