@@ -194,3 +194,37 @@ def test_device_error_word_is_reported_by_the_next_call(cuda):
     gd.apply_(T, phi, eng.sqnorm)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(T).all())
+
+
+def test_window_half_width_follows_the_documented_rule(cuda):
+    """The predictor on the device (spec_update_dev, steinhip.hip): the next half-width is max(4 * |this step's prediction
+    error| + 48, 3/4 of the last half-width that was itself earned from an error) -- the 4096-key window of a predictor
+    without a velocity does not count -- capped at 32767.  Replayed here from the state words of consecutive steps."""
+    n, d = 2048, 32
+    g = torch.Generator(device="cpu").manual_seed(5)
+    T = torch.randn(n, d, generator=g).to(cuda)
+    G = torch.randn(n, d, generator=g).to(cuda)
+    eng = SvgdEngine(n, d, device=cuda)
+    _, offs, _ = _lib.workspace_layout(eng.n_local, eng.n, eng.d, flags=eng.flags)
+    o = offs[_lib.WS_SELECT] + 64
+
+    def words():
+        torch.cuda.synchronize()
+        return eng.ws[o:o + 64].cpu().numpy().view(np.uint32).astype(np.int64)
+
+    prev, checked, shrank_by_floor = None, 0, 0
+    for step in range(40):
+        eng.compute_phi(T, G)
+        u = words()   # [1] centre of the NEXT window, [2] its half-width, [4] this step's width, [8] earned half-width, [12] this step's key
+        if prev is not None and prev[0] == 0x5EED0002 and u[4] != 0:      # the window of this step was a real prediction
+            err = abs(int(u[12]) - int(prev[1]))
+            want = 32767 if err > 32767 // 4 else 4 * err + 48
+            want = max(want, int(prev[8]) - int(prev[8]) // 4)
+            if not (u[7] and u[5] > ((1 << 21) - 2048) // 2):              # (the "keep the buffer small" halving: not at this size)
+                assert int(u[2]) == min(want, 32767), (step, err, int(prev[8]), int(u[2]))
+                assert int(u[8]) == min(want, 32767)
+                checked += 1
+                shrank_by_floor += int(want > 4 * err + 48)
+        prev = u
+        T = T + 1e-2 * torch.randn(n, d, generator=g).to(cuda) + 2e-3     # a noisy drift: the errors jump around
+    assert checked >= 30 and shrank_by_floor >= 3, (checked, shrank_by_floor)
