@@ -1399,6 +1399,9 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
     const double eff = rounds / ceil(rounds) - 0.004 * (double)(s - 1);
     if (eff > best + 1e-9) { best = eff; split = s; }
   }
+#ifdef STEIN_FORCE_SPLIT   // (diagnostic builds: scratch/build_variant.py splitN -DSTEIN_FORCE_SPLIT=N)
+  split = STEIN_FORCE_SPLIT <= max_split ? STEIN_FORCE_SPLIT : max_split;
+#endif
   int64_t tiles_per = (jt + split - 1) / split;
   if (x3) tiles_per = (tiles_per + 3) / 4 * 4;   // a j range of the split kernel starts on a multiple of 128 columns (its
                                                  // pipeline stages then never straddle a row tile's diagonal block)
