@@ -230,6 +230,7 @@ def test_column_maxima_paths_agree(cuda):
     G = torch.tensor(G64 * 1e-3, dtype=torch.float32, device=cuda)
     eng = SvgdEngine(n, d, device=cuda, x3=True, small=False)
     st = eng.stages
+    eng.planes.zero_()                            # (the section has padding that nothing writes)
     st.x3_prepare(T, G, n, d, eng.planes)
     torch.cuda.synchronize()
     aligned = eng.planes.clone()
