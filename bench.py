@@ -25,6 +25,14 @@ on), `frac` = achieved / peak (= `frac_algorithmic`).  The split path executes 3
 `frac_vs_fp32_mfma_peak` the algorithmic flops against the 157.3 TFLOP/s fp32-input MFMA peak (what an fp32 GEMM could
 reach at most); the strict fp32-input MFMA kernels are timed under `fp32_path`.
 
+Headline timing (one rank): `ms_per_step` / `value` come from a timed loop of exactly K steps that carries two HIP events per
+step (they bracket the contraction: `roofline.ms_per_launch`, measured live); `stage_ms`, `events_ms`, `wall_minus_events_ms` and
+`instrumented_ms_per_step` come from a second loop of K steps with an event at every stage boundary.  An event between two kernels
+costs the step ~3 us of GPU time (scratch/event_cost.py): eight of them are 2.5 % of a C3 step and a quarter of a C2 step.
+Behind the W warm-up steps the same loop keeps running untimed until 80 ms of load have passed (`settle_steps` says how many
+steps that took): the chip's clock governor settles under this load in ~50 ms, and the 20 steps behind a 5-step warm-up alone
+are 8 % slower than every later block of 20 (scratch/step_trend.py); `first_block_ms_per_step` is that block, timed on the side.
+
 wall_minus_events_ms (every timed entry): wall time per step minus the GPU time the HIP events of the same steps bracket;
 `host_stall_suspected` when the gap exceeds max(0.03 ms, 4 %) (a healthy C3 loop shows 0.012 ms).  A stalled timed loop
 (headline or variant) is timed again, at most twice; the line carries the run with the smallest wall time and `retimed` lists
@@ -99,6 +107,9 @@ class StageClock:
         return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
+SETTLE_MS = 80.0    # untimed load in front of a light run's timed loop (see run_workload)
+
+
 def gap_fields(wall_ms, events_ms):
     """Wall time per step against the GPU time the HIP events of the same steps bracket (the library's stage events plus the
     apply kernel's pair; they do not cover the host's time BETWEEN two steps): a gap means the host, not the GPU, set the
@@ -108,6 +119,30 @@ def gap_fields(wall_ms, events_ms):
     gap = wall_ms - events_ms
     return {"events_ms": round(events_ms, 4), "wall_minus_events_ms": round(gap, 4),
             "host_stall_suspected": bool(gap > max(0.03, 0.04 * events_ms))}
+
+
+def headline_gap(ms_per_step, res, steps):
+    """The gap fields of the headline entry.  One rank: the timed loop carries only the contraction's two events, so the stage
+    split, `events_ms` and `wall_minus_events_ms` describe the SECOND loop (every stage event; `instrumented_ms_per_step` is its
+    wall time per step), and `host_stall_suspected` says whether the timed loop was slower than that one allows."""
+    if res.get("instr_elapsed") is None:
+        return gap_fields(ms_per_step, res["events_ms"])
+    instr_ms = res["instr_elapsed"] / steps * 1e3
+    g = gap_fields(instr_ms, res["events_ms"])
+    ref_ms = min(instr_ms, res["events_ms"])
+    g["host_stall_suspected"] = bool(g["host_stall_suspected"] or ms_per_step > ref_ms + max(0.03, 0.04 * res["events_ms"]))
+    g["instrumented_ms_per_step"] = round(instr_ms, 4)
+    g["settle_steps"] = res.get("settle_steps")
+    g["first_block_ms_per_step"] = round(res["first_block_ms"], 4) if res.get("first_block_ms") else None
+    g["timing_note"] = ("ms_per_step / value: the timed loop, which carries two HIP events per step (around the contraction: "
+                        "roofline.ms_per_launch).  stage_ms / events_ms / wall_minus_events_ms / instrumented_ms_per_step: a second "
+                        "loop of the same steps with an event at every stage boundary -- each event between two kernels costs "
+                        "~3 us of GPU time, so that loop is slower than the one it explains.  settle_steps: untimed steps of the same "
+                        "loop run behind the W warm-up steps until %g ms of load have passed since the first one (the clock governor "
+                        "settles under this load in ~50 ms; the 20 steps behind a 5-step warm-up alone are 8 %% slower than every "
+                        "later block of 20, scratch/step_trend.py).  first_block_ms_per_step: the first `steps` of those settle steps, "
+                        "timed on the side without any event: what a measurement right behind the W warm-up steps reads" % SETTLE_MS)
+    return g
 
 
 def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
@@ -129,7 +164,12 @@ def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
 
 
 def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clock_stages=True, x3=None, window=True,
-                 comm="torch", tile_distance=False):
+                 comm="torch", tile_distance=False, light=False):
+    """light (one rank): the timed loop carries only the two HIP events that bracket the contraction (the roofline's kernel time,
+    measured live); the full stage split comes from a second loop of the same number of steps right behind it, with every stage
+    event and the apply kernel's pair.  A HIP event between two kernels costs the step ~3 us of GPU time (scratch/event_cost.py:
+    eight of them are 2.5 % of a C3 step and a quarter of a C2 step), so the loop whose wall time is the headline should not
+    be the one that carries them."""
     from stein_amd import _lib
     from stein_amd.engine import SvgdEngine
     from stein_amd.optimizers import AdagradGradientDescent
@@ -164,14 +204,16 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     # (STEIN_FLAG_TIMING): at every stage boundary of the fused call, around the contraction and the finish pass of a
     # sharded step (the other stages of a sharded step are separated by collectives and are not split here).
     fused = True
+    light = bool(light and world == 1 and clock_stages)
     apply_events = []
     if fused and clock_stages:
         _lib.timing_reserve(steps)
+    full_events = [not light]          # (rebound for the second, fully instrumented loop of a light run)
 
     def step(timed):
         if fused:
-            phi = eng.compute_phi(feed(), G, timing=timed and clock_stages)
-            if timed and clock_stages:
+            phi = eng.compute_phi(feed(), G, timing=(True if full_events[0] else "contract") if (timed and clock_stages) else False)
+            if timed and clock_stages and full_events[0]:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 gd.apply_(theta, phi, eng.sqnorm)
@@ -188,8 +230,29 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
             phi = eng.compute_phi(feed(), G, mark=(lambda s: None) if clock_stages else None)
             gd.apply_(theta, phi, eng.sqnorm)
 
+    t_warm = time.perf_counter()
     for _ in range(warmup):
         step(False)
+    # light runs: the chip's clock governor needs ~50 ms of THIS load to settle -- the 20 steps that follow a 5-step warm-up
+    # are 8 % slower than every later block of 20 (contraction 0.65 -> 0.61 ms; scratch/step_trend.py), and a generic load
+    # beforehand settles only half of it.  More untimed steps of the same loop follow the W warm-up steps until 80 ms have
+    # passed since the first one; how many is reported (`settle_steps`).
+    settle_steps = 0
+    first_block_ms = None
+    if light:
+        # (the first `steps` of them are timed on the side: what a measurement right behind the W warm-up steps reads)
+        torch.cuda.synchronize(device)
+        tb = time.perf_counter()
+        for _ in range(steps):
+            step(False)
+        torch.cuda.synchronize(device)
+        first_block_ms = (time.perf_counter() - tb) / steps * 1e3
+        settle_steps = steps
+        while (time.perf_counter() - t_warm) * 1e3 < SETTLE_MS and settle_steps < 2000:
+            for _ in range(10):
+                step(False)
+            settle_steps += 10
+            torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier(group=group)
     torch.cuda.synchronize(device)
@@ -208,6 +271,19 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
         dist.all_reduce(te, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(te.item())
     stats1 = eng.window_stats() if has_window else (0, 0)
+    contract_live = instr_elapsed = None
+    if light:
+        per_call = _lib.timing_read(steps)
+        contract_live = sum(c["contract"] for c in per_call) / max(1, len(per_call))
+        # the second loop: the same steps with every stage event (not part of `elapsed`)
+        full_events[0] = True
+        _lib.timing_reserve(steps)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        torch.cuda.synchronize(device)
+        instr_elapsed = time.perf_counter() - t1
     if fused and clock_stages:
         per_call = _lib.timing_read(steps)
         stages = {k: round(sum(c[k] for c in per_call) / max(1, len(per_call)), 4) for k in _lib.T_STAGES
@@ -231,6 +307,7 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     relerr, nrows = parity_sample(torch, T_all, G_all, phi, row0, float(eng.h2.item()))
     crosscheck = None
     return dict(comm=eng.comm, comm_note=comm_note, comm_crosscheck=crosscheck, n=n, d=d, n_local=n_local, elapsed=elapsed, stages=stages, events_ms=events_ms, finite=finite, split=eng.split,
+                contract_live_ms=contract_live, instr_elapsed=instr_elapsed, settle_steps=settle_steps, first_block_ms=first_block_ms,
                 ws_bytes=eng.ws_bytes, T64=T64, G64=G64, x3=eng.x3, parity_relerr=relerr, parity_rows=nrows,
                 window=dict(timed_steps=stats1[0] - stats0[0], hits=stats1[1] - stats0[1]) if has_window else None)
 
@@ -240,7 +317,16 @@ def run_stable(torch, dist, wl, device, rank, world, group, steps, warmup, **kw)
     per step beyond the event-bracketed GPU time by more than max(0.03 ms, 4 %): a launch thread that lost its core on a shared
     box).  Keeps the run with the smallest wall time.  -> (result, None | what the other runs measured)"""
     res = run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, **kw)
-    stalled = lambda r: gap_fields(r["elapsed"] / steps * 1e3, r["events_ms"])["host_stall_suspected"]
+
+    def stalled(r):
+        if r.get("instr_elapsed") is None:
+            return gap_fields(r["elapsed"] / steps * 1e3, r["events_ms"])["host_stall_suspected"]
+        # a light run: its timed loop carries two events per step; it must not be slower than the loop with all of them
+        # behind it, nor than that loop's event-bracketed GPU time by more than the usual margin
+        instr = gap_fields(r["instr_elapsed"] / steps * 1e3, r["events_ms"])
+        ref_ms = min(r["instr_elapsed"] / steps * 1e3, r["events_ms"])
+        return bool(instr["host_stall_suspected"] or r["elapsed"] / steps * 1e3 > ref_ms + max(0.03, 0.04 * r["events_ms"]))
+
     if world != 1 or not stalled(res):
         return res, None
     others = []
@@ -493,12 +579,15 @@ def main():
     hx3 = False if args.fp32_mfma else None
     # (a stalled timed loop -- a launch thread that lost its core on a shared box -- is timed once more; `retimed` keeps the
     # first run's numbers)
-    res, retimed = run_stable(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3)
+    res, retimed = run_stable(torch, dist, wl, device, rank, world, group, args.steps, args.warmup, comm=args.comm, x3=hx3,
+                              light=True)
     n, d, nl = res["n"], res["d"], res["n_local"]
     ms_per_step = res["elapsed"] / args.steps * 1e3
     value = n * args.steps / res["elapsed"]
     nprod = (1 if wl.get("bf16") else 3) if res["x3"] else 1     # 16-bit MFMA products per operand pair
-    k_ms = res["stages"].get("contract")
+    # the contraction's mean launch time: from the two events that bracket it inside the timed loop (one rank), else from
+    # the stage events
+    k_ms = res["contract_live_ms"] if res.get("contract_live_ms") else res["stages"].get("contract")
     flops = 4.0 * nl * n * d
     alg = flops / (k_ms * 1e-3) if k_ms else None
     traffic, traffic_src, mfma_busy, pmc_ent = pmc_traffic(args.workload, res["x3"]) if world == 1 else (None, None, None, {})
@@ -563,7 +652,7 @@ def main():
         "roofline": roof,
         "gemm_path": ({1: "bf16 inputs (1 product)", 3: "split fp16 x 2 (3 products)"}[nprod]) if res["x3"] else "fp32 mfma",
         "stage_ms": {k: round(v, 4) for k, v in res["stages"].items()},
-        **gap_fields(ms_per_step, res["events_ms"]),
+        **headline_gap(ms_per_step, res, args.steps),
         "retimed": retimed,
         "window": res["window"],
         "full_step_tflops": 6.0 * nl * n * d / (ms_per_step * 1e-3) / 1e12,

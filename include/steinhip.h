@@ -56,8 +56,11 @@ enum {
                                 passes over D on every call (same result; what a window miss costs, for measurements) */
   STEIN_FLAG_RANK_WINDOW = 32, /* stein_rank_* only: this step uses the cross-rank speculative window (tally / pick) instead
                                   of the radix-select histograms */
-  STEIN_FLAG_TILE_DISTANCE = 64 /* stein_svgd_phi only: run the distance pass with the per-tile kernel even where the
-                                   panel-resident form (STEIN_STAGE_TILES below) would be taken; for A/B measurements */
+  STEIN_FLAG_TILE_DISTANCE = 64, /* stein_svgd_phi only: run the distance pass with the per-tile kernel even where the
+                                    panel-resident form (STEIN_STAGE_TILES below) would be taken; for A/B measurements */
+  STEIN_FLAG_TIMING_CONTRACT = 128 /* stein_svgd_phi, with STEIN_FLAG_TIMING: record only the two events that bracket the
+                                      contraction (an event between two kernels costs the step ~3 us of GPU time: six of
+                                      them perturb what they time); stein_timing_read reports -1 for the other stages */
 };
 /* flags for the staged distance / histogram calls */
 enum {

@@ -28,6 +28,7 @@ FLAG_TILED = 8
 FLAG_NO_WINDOW = 16
 FLAG_RANK_WINDOW = 32
 FLAG_TILE_DISTANCE = 64
+FLAG_TIMING_CONTRACT = 128
 GLM_LINEAR, GLM_LOGISTIC = 0, 1
 SPEC_TABLE_WORDS = 65544          # uint64 words of the rank-summed window table ...
 SPEC_TABLE_OFFSET_WORDS = 1 << 21  # ... which starts 2^21 words into the SPEC section (slots + entry buffer)

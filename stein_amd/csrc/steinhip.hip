@@ -1373,7 +1373,7 @@ int stein_make_layout(int64_t n_local, int64_t n, int64_t d, int dtype, int flag
   if (d < 1 || n_local < 1 || n_local > n) return fail(STEIN_E_SHAPE, "bad shape n_local=%lld n=%lld d=%lld", (long long)n_local, (long long)n, (long long)d);
   if (n > (1ll << 30) || d > (1ll << 24) || n * d > (1ll << 40)) return fail(STEIN_E_SHAPE, "shape too large");
   if (dtype != STEIN_F32 && dtype != STEIN_BF16) return fail(STEIN_E_UNSUPPORTED, "dtype %d", dtype);
-  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW | STEIN_FLAG_TILE_DISTANCE)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
+  if (flags & ~(STEIN_FLAG_X3 | STEIN_FLAG_TIMING | STEIN_FLAG_TILED | STEIN_FLAG_NO_WINDOW | STEIN_FLAG_RANK_WINDOW | STEIN_FLAG_TILE_DISTANCE | STEIN_FLAG_TIMING_CONTRACT)) return fail(STEIN_E_BADARG, "unknown flags 0x%x", flags);
   L->ld_dist = (int64_t)align_up((size_t)n, 64);
   L->tiles_m = (n_local + BM - 1) / BM;
   L->cblocks = (d + BN - 1) / BN;
@@ -1781,6 +1781,7 @@ extern "C" int stein_kernel_contract(const float* dist, int64_t ld_dist, const v
 // ------------------------------------------------------------------------------------------------
 static thread_local std::vector<hipEvent_t> g_tevents;   // (STEIN_T_NSTAGES + 1) events per reserved call
 static thread_local int g_tcalls_reserved = 0, g_tcalls_used = 0;
+static thread_local std::vector<unsigned char> g_tmode;   // per reserved call: 1 = only the contraction was bracketed
 
 struct RankViews {
   SteinLayout L;
@@ -1864,8 +1865,10 @@ extern "C" int stein_rank_finish(const void* theta_all, const void* score_all, i
   // STEIN_FLAG_TIMING: the contraction and the finish pass are bracketed by HIP events on the stream (the earlier
   // stages of the slot read as zero length); read them back with stein_timing_read
   hipEvent_t* tev = nullptr;
-  if ((flags & STEIN_FLAG_TIMING) && g_tcalls_used < g_tcalls_reserved)
+  if ((flags & STEIN_FLAG_TIMING) && g_tcalls_used < g_tcalls_reserved) {
+    g_tmode[(size_t)g_tcalls_used] = 0;
     tev = &g_tevents[(size_t)(g_tcalls_used++) * (STEIN_T_NSTAGES + 1)];
+  }
   if (tev)
     for (int k = 0; k <= STEIN_T_CONTRACT; ++k) HIP_TRY(hipEventRecord(tev[k], (hipStream_t)stream));
   if ((rc = stein_contract_partial(v.D, v.L.ld_dist, theta_all, score_all, n, d, row0, n_local, dtype, h2_dev, v.planes,
@@ -1949,6 +1952,7 @@ extern "C" int stein_timing_reserve(int calls) {
     HIP_TRY(hipEventCreate(&e));
     g_tevents.push_back(e);
   }
+  g_tmode.assign((size_t)calls, 0);
   g_tcalls_reserved = calls;
   g_tcalls_used = 0;
   return STEIN_OK;
@@ -1959,6 +1963,12 @@ extern "C" int stein_timing_read(float* ms_out, int max_calls, int* calls_out) {
   const int calls = g_tcalls_used < max_calls ? g_tcalls_used : max_calls;
   for (int c = 0; c < calls; ++c) {
     hipEvent_t* ev = &g_tevents[(size_t)c * (STEIN_T_NSTAGES + 1)];
+    if (g_tmode[(size_t)c]) {   // STEIN_FLAG_TIMING_CONTRACT: the other stages were not bracketed
+      HIP_TRY(hipEventSynchronize(ev[STEIN_T_FINISH]));
+      for (int k = 0; k < STEIN_T_NSTAGES; ++k) ms_out[c * STEIN_T_NSTAGES + k] = -1.f;
+      HIP_TRY(hipEventElapsedTime(&ms_out[c * STEIN_T_NSTAGES + STEIN_T_CONTRACT], ev[STEIN_T_CONTRACT], ev[STEIN_T_FINISH]));
+      continue;
+    }
     HIP_TRY(hipEventSynchronize(ev[STEIN_T_NSTAGES]));
     for (int k = 0; k < STEIN_T_NSTAGES; ++k) HIP_TRY(hipEventElapsedTime(&ms_out[c * STEIN_T_NSTAGES + k], ev[k], ev[k + 1]));
   }
@@ -1993,9 +2003,14 @@ extern "C" int stein_svgd_phi(const void* theta_all, const void* score_all, int6
   u64* spec_buf = (u64*)(ws + L.off[STEIN_WS_SPEC]);
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t* tev = nullptr;   // STEIN_FLAG_TIMING: one event per stage boundary, while reserved slots last
-  if ((flags & STEIN_FLAG_TIMING) && g_tcalls_used < g_tcalls_reserved)
+  // (STEIN_FLAG_TIMING_CONTRACT: only the two events around the contraction -- an event between two kernels costs the step
+  // ~3 us of GPU time, scratch/event_cost.py: six of them are 2 % of a C3 step and a quarter of a C2 step)
+  const bool tonly = (flags & STEIN_FLAG_TIMING_CONTRACT) != 0;
+  if ((flags & STEIN_FLAG_TIMING) && g_tcalls_used < g_tcalls_reserved) {
+    g_tmode[(size_t)g_tcalls_used] = tonly ? 1 : 0;
     tev = &g_tevents[(size_t)(g_tcalls_used++) * (STEIN_T_NSTAGES + 1)];
-#define STEIN_TSTAMP(k) do { if (tev) HIP_TRY(hipEventRecord(tev[k], s)); } while (0)
+  }
+#define STEIN_TSTAMP(k) do { if (tev && (!tonly || (k) == STEIN_T_CONTRACT || (k) == STEIN_T_FINISH)) HIP_TRY(hipEventRecord(tev[k], s)); } while (0)
   STEIN_TSTAMP(STEIN_T_PREPARE);
   if (!(flags & STEIN_FLAG_TILED) && stein_small_ok(n, d, dtype)) {   // the reference's own example sizes: one kernel does it all (stein_small.hip)
     STEIN_TSTAMP(STEIN_T_DISTANCE);

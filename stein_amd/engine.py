@@ -487,7 +487,8 @@ class SvgdEngine:
         window of the fused call needs state that persists inside one workspace, see stein_common.h).
         timing: let the library record HIP events on the stream at its stage boundaries (_lib.timing_reserve /
         _lib.timing_read): every stage of the fused call on a single rank, the contraction and the finish pass in a
-        sharded step.
+        sharded step.  timing="contract" (single rank): only the two events around the contraction -- every event between two
+        kernels costs the step ~3 us, so a loop that is itself being timed should carry as few as it can.
         """
         st, n, d, nl = self.stages, self.n, self.d, self.n_local
         for name, t in (("theta", theta_local), ("score", score_local)):
@@ -496,7 +497,8 @@ class SvgdEngine:
                                  (name, self.dtype, nl, d, tuple(t.shape), t.dtype))
         if not self.sharded and mark is None:
             st.svgd_phi(theta_local, score_local, n, d, self.phi, self.h2, self.sqnorm, K_out, dK_out, self.ws,
-                        self.flags | (_lib.FLAG_TIMING if timing else 0))
+                        self.flags | (_lib.FLAG_TIMING if timing else 0) |
+                        (_lib.FLAG_TIMING_CONTRACT if timing == "contract" else 0))
             self._have_dist = not self._one_kernel
             self.dist_upper = self.x3 and self._have_dist and not SvgdEngine._full_distance_image
             return self.phi
