@@ -108,6 +108,7 @@ class StageClock:
 
 
 SETTLE_MS = 80.0    # untimed load in front of a light run's timed loop (see run_workload)
+SETTLE_STEPS_MULTI = 60   # the same for a sharded run, as a step count that is equal on every rank
 
 
 def gap_fields(wall_ms, events_ms):
@@ -126,7 +127,9 @@ def headline_gap(ms_per_step, res, steps):
     split, `events_ms` and `wall_minus_events_ms` describe the SECOND loop (every stage event; `instrumented_ms_per_step` is its
     wall time per step), and `host_stall_suspected` says whether the timed loop was slower than that one allows."""
     if res.get("instr_elapsed") is None:
-        return gap_fields(ms_per_step, res["events_ms"])
+        g = gap_fields(ms_per_step, res["events_ms"])
+        g["settle_steps"] = res.get("settle_steps")
+        return g
     instr_ms = res["instr_elapsed"] / steps * 1e3
     g = gap_fields(instr_ms, res["events_ms"])
     ref_ms = min(instr_ms, res["events_ms"])
@@ -253,6 +256,11 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
                 step(False)
             settle_steps += 10
             torch.cuda.synchronize(device)
+    if world > 1 and clock_stages:
+        # several ranks: a FIXED number of settle steps (every rank must take the same number of steps: each holds collectives)
+        for _ in range(SETTLE_STEPS_MULTI):
+            step(False)
+        settle_steps = SETTLE_STEPS_MULTI
     if world > 1:
         dist.barrier(group=group)
     torch.cuda.synchronize(device)
