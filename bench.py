@@ -167,7 +167,7 @@ def parity_sample(torch, T_all, G_all, phi_local, row0, h2, n_rows=48):
 
 
 def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clock_stages=True, x3=None, window=True,
-                 comm="torch", tile_distance=False, light=False):
+                 comm="torch", tile_distance=False, light=False, settle=False):
     """light (one rank): the timed loop carries only the two HIP events that bracket the contraction (the roofline's kernel time,
     measured live); the full stage split comes from a second loop of the same number of steps right behind it, with every stage
     event and the apply kernel's pair.  A HIP event between two kernels costs the step ~3 us of GPU time (scratch/event_cost.py:
@@ -242,7 +242,7 @@ def run_workload(torch, dist, wl, device, rank, world, group, steps, warmup, clo
     # passed since the first one; how many is reported (`settle_steps`).
     settle_steps = 0
     first_block_ms = None
-    if light:
+    if light or (settle and world == 1):
         # (the first `steps` of them are timed on the side: what a measurement right behind the W warm-up steps reads)
         torch.cuda.synchronize(device)
         tb = time.perf_counter()
@@ -769,11 +769,12 @@ def main():
             torch.cuda.empty_cache()
             # the step time without stage events in the loop (at these sizes the event records are not free), then a
             # short run with them for the stage split
-            ro = run_workload(torch, dist, dict(WORKLOADS[key]), device, rank, world, group, 20, 3, clock_stages=False)
+            ro = run_workload(torch, dist, dict(WORKLOADS[key]), device, rank, world, group, 20, 3, clock_stages=False, settle=True)
             rs = run_workload(torch, dist, dict(WORKLOADS[key]), device, rank, world, group, 8, 3)
             others[key] = {"workload": WORKLOADS[key]["name"], "n": ro["n"], "d": ro["d"], "steps": 20,
                            "ms_per_step": ro["elapsed"] / 20 * 1e3, "value": ro["n"] * 20 / ro["elapsed"],
                            "unit": "particle-updates/s", "finite": ro["finite"],
+                           "settle_steps": ro["settle_steps"], "first_block_ms_per_step": round(ro["first_block_ms"], 4),
                            "stage_ms": {k: round(v, 4) for k, v in rs["stages"].items()},
                            "staged_run_ms_per_step": rs["elapsed"] / 8 * 1e3,   # the 8-step run that carried the stage events
                            **gap_fields(rs["elapsed"] / 8 * 1e3, rs["events_ms"]),
