@@ -611,12 +611,15 @@ def main():
             "frac_executed": nprod * alg / PEAK_16BIT_MFMA if alg else None,
             "executed_tflops": nprod * alg / 1e12 if alg else None,
             "mfma_busy_frac": mfma_busy,
+            "mfma_busy_measured_at_ms_per_launch": (round(pmc_ent["k_phi_x3fs_avg_ns_rocprofv3"] / 1e6, 4)
+                                                    if pmc_ent.get("k_phi_x3fs_avg_ns_rocprofv3") else None),
             "frac_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA if alg else None,
             "note": "achieved / frac = frac_algorithmic = the ALGORITHMIC 4 n_local n d flops of SURVEY 8(d) / mean kernel time / the "
                     "dense fp16/bf16 MFMA peak (the pipe the kernel runs on).  frac_executed = the 16-bit MFMA flops the kernel "
                     "EXECUTES (%d products per fp32 operand pair x the algorithmic flops) against the same peak: the utilisation "
                     "of that pipe.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x 2.4 GHz x kernel time) from the "
-                    "committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), an independent reading of frac_executed.  "
+                    "committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), an independent reading of frac_executed AT THAT PASS'S launch time (mfma_busy_measured_at_ms_per_launch: the profiler's launches "
+                    "are slower than the settled timed loop's, so it reads lower than frac_executed here).  "
                     "frac_vs_fp32_mfma_peak = the algorithmic flops against the 157.3 TFLOP/s fp32-input MFMA peak (SURVEY 7: a "
                     "split emulation is also reported against the fp32 peak; > 1 means faster than any fp32-MFMA GEMM)" % nprod,
             "fp32_equivalent_tflops": alg / 1e12 if alg else None,
