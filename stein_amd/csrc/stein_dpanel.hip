@@ -426,11 +426,11 @@ __global__ __launch_bounds__(DP_THREADS, 2) void k_distance_panel(const u16* __r
         for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // In its k loop a wave outranks the wave of its SIMD that is in an epilogue: MFMAs and VALU instructions are issued
-        // through one port, the arbiter prefers the OLDER wave at equal priority, and an older wave in its epilogue -- a
-        // stream of VALU instructions, one every four cycles -- kept the younger one's MFMAs waiting: every epilogue
-        // instruction cost ~3 cycles of matrix-pipe time (counters, round 4: the pipe 0.63 busy with the epilogue, 0.86 without).
-        // With the ranks set, the epilogue's instructions fill the twelve free issue cycles behind each MFMA instead.
+        // In its k loop a wave outranks the wave of its SIMD that is in an epilogue.  The idea -- an older wave's stream of
+        // epilogue VALU instructions keeps the younger one's MFMAs waiting at the shared issue port -- did not survive the
+        // measurements: another wave's plain VALU, scalar and LDS instructions cost the matrix pipe nothing
+        // (scratch/coissue_probe.hip), and with / without these two s_setprio the pass takes 0.2034 / 0.2027 ms unsettled and
+        // 0.1877 / 0.1891 ms settled (scratch/ab_fused.py): inside the noise, kept because it never loses.
         DP_SETPRIO(2);
         for (int g = 0; g < groups; ++g) {
           const bool last = g + 1 >= groups;
