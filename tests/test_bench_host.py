@@ -34,3 +34,17 @@ def test_workloads_are_the_baseline_configs():
     assert (bench.WORKLOADS["c4"]["n"], bench.WORKLOADS["c4"]["d"]) == (8192, 2001)
     assert (bench.WORKLOADS["c5"]["n"], bench.WORKLOADS["c5"]["d"]) == (131072, 256)
     assert bench.PEAK_16BIT_MFMA == 2.5e15 and bench.PEAK_FP32_MFMA == 157.3e12
+
+
+def test_headline_gap_describes_the_instrumented_loop_and_flags_a_slow_timed_loop():
+    # a light run: the timed loop (two events per step) must not be slower than the fully instrumented loop behind it
+    res = dict(instr_elapsed=20 * 0.9209e-3, events_ms=0.9084, settle_steps=80, first_block_ms=0.9838)
+    ok = bench.headline_gap(0.9029, res, 20)
+    assert ok["host_stall_suspected"] is False and ok["instrumented_ms_per_step"] == 0.9209
+    assert abs(ok["wall_minus_events_ms"] - (0.9209 - 0.9084)) < 1e-9 and ok["settle_steps"] == 80
+    assert ok["first_block_ms_per_step"] == 0.9838 and "timing_note" in ok
+    slow = bench.headline_gap(0.9738, res, 20)                 # round 4: the timed loop ran in the unsettled first block
+    assert slow["host_stall_suspected"] is True
+    # several ranks (no second loop): the plain gap fields plus the settle count
+    multi = bench.headline_gap(0.30, dict(instr_elapsed=None, events_ms=None, settle_steps=60), 20)
+    assert multi["settle_steps"] == 60 and multi["host_stall_suspected"] is None
